@@ -1,0 +1,171 @@
+/*
+ * scone_hip.h -- C-ABI of libscone_hip.so: the MI355X (gfx950) implementation of SCoNe's
+ * Hodge-Laplacian convolution hot path.
+ *
+ * The reference (nglaze00/SCoNe_GCN) has no FFI: the path is plain Python/JAX.  Each entry point below
+ * names the reference code it replaces (TE = trajectory_analysis/trajectory_experiments.py,
+ * STM = trajectory_analysis/scone_trajectory_model.py).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = SCN_OK, negative = error (scn_error_string()).
+ *     No C++ exception crosses this boundary.
+ *   - "device" pointers are HIP device memory owned by the CALLER (PyTorch-ROCm tensors in the host
+ *     mirror); the library never allocates per call.  Handles own only the device copies of the index /
+ *     value arrays made at create time and are immutable afterwards (shareable across streams).
+ *   - all launches go to the caller's stream (hipStream_t passed as void*; NULL = default stream) and
+ *     never synchronise.
+ *
+ * Activation layout ("flow slabs"): fp32 [n_slabs][n_rows][ns][c] row-major.  A slab holds ns
+ * trajectories; row r of slab s is the contiguous piece of ns*c floats at ((s*n_rows + r)*ns)*c.
+ * The reference's batched (N, E, C) tensor (vmap axis 0, STM:256) maps to slab = n / ns, sample = n % ns.
+ */
+#ifndef SCONE_HIP_H
+#define SCONE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCN_OK               0
+#define SCN_ERR_BAD_ARG     -1
+#define SCN_ERR_BAD_SHAPE   -2
+#define SCN_ERR_HIP         -3
+#define SCN_ERR_UNSUPPORTED -4
+#define SCN_ERR_NOMEM       -5
+#define SCN_ERR_WORKSPACE   -6
+
+/* activation codes (TE:124-134) */
+#define SCN_ACT_NONE        0
+#define SCN_ACT_TANH        1   /* scone   TE:149 */
+#define SCN_ACT_RELU        2   /* bunch   TE:195 */
+#define SCN_ACT_LEAKY_RELU  3   /* ebli    TE:167, slope 0.01, x >= 0 */
+
+#define SCN_MAX_GROUPS 3
+#define SCN_MAX_SLOTS  4
+
+int         scn_version(void);
+const char* scn_error_string(int status);
+/* last HIP error text captured by a failing call on this thread ("" if none) */
+const char* scn_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Shift-convolution operator: everything that feeds ONE output level of one layer.
+ *
+ *   out[s,r,n,:] = act( sum_over_slots  ( sum_j val_slot[r,j] * src_g[s, col[r,j], n, :] ) @ W_slot )
+ *
+ * A group g is one source tensor + one CSR pattern (n_rows x n_cols) carrying 1 or 2 value arrays and,
+ * optionally, an identity shift.  Weight slots are numbered group by group: [identity][val0][val1].
+ *   scone / ebli layer (TE:145-147 / 163-165): 1 group, identity + {S_lower, S_upper} on their shared
+ *       pattern -> slots (W[3i], W[3i+1], W[3i+2]).
+ *   bunch node / edge / face level (TE:184-192): 2 / 3 / 2 groups with 1 value array each.
+ * Host arrays are copied at create time.
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct scn_conv_s* scn_conv_t;
+
+typedef struct {
+    int32_t        n_cols;    /* rows of this group's source tensor */
+    int32_t        identity;  /* 1: also apply the identity shift (needs n_cols == n_rows) */
+    int32_t        n_vals;    /* 0, 1 or 2 value arrays on the pattern (0 only with identity) */
+    int32_t        reserved;
+    int64_t        nnz;
+    const int32_t* rowptr;    /* host, n_rows + 1 */
+    const int32_t* col;       /* host, nnz, ascending within a row */
+    const float*   val0;      /* host, nnz (or NULL when n_vals == 0) */
+    const float*   val1;      /* host, nnz (or NULL when n_vals < 2) */
+} scn_group_desc;
+
+int scn_conv_create(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups, scn_conv_t* out);
+int scn_conv_destroy(scn_conv_t conv);
+int scn_conv_n_slots(scn_conv_t conv);
+/* rows per LDS-staged block and mean staged source rows per block of the blocked plan (0 if none) */
+int scn_conv_plan_info(scn_conv_t conv, int32_t* n_blocks, float* mean_sources_per_row);
+
+/* Forward of one output level (replaces the body of the layer loops TE:144-149, 162-167, 181-195).
+ *   src[g]  device [n_slabs][n_cols_g][ns][c_in[g]]
+ *   W[slot] device [c_in(group of slot)][c_out] row-major
+ *   out     device [n_slabs][n_rows][ns][c_out]                                                  */
+int scn_conv_forward(scn_conv_t conv, int32_t n_slabs, int32_t ns,
+                     const float* const* src, const int32_t* c_in,
+                     const float* const* W, int32_t c_out, int32_t act,
+                     float* out, void* stream);
+
+/* Backward of one INPUT level (what jax.grad generates for the same loops, STM:307).  `conv_t` is the
+ * operator whose slots are the TRANSPOSED shifts feeding this input level (for scone's symmetric
+ * L_lower / L_upper it is the forward object itself).
+ *   dz[g]    device [n_slabs][n_cols_g][ns][c_dz[g]]   grad w.r.t. the pre-activation of output level g
+ *   W[slot]  device [c_aux][c_dz(group of slot)]        the FORWARD weights (used transposed)
+ *   aux      device [n_slabs][n_rows][ns][c_aux]        this level's forward input (= previous layer's output)
+ *   dx       device [n_slabs][n_rows][ns][c_aux] or NULL:
+ *               dx = ( sum_slots G_slot @ W_slot^T ) * act'(aux)    with G_slot the gathered dz
+ *   dW[slot] device [c_aux][c_dz]   dW_slot += sum_{s,r,n} aux[s,r,n,:]^T G_slot[s,r,n,:]   (deterministic order)
+ *   workspace: device scratch of at least scn_conv_backward_workspace() bytes                       */
+size_t scn_conv_backward_workspace(scn_conv_t conv_t, int32_t n_slabs, int32_t ns,
+                                   const int32_t* c_dz, int32_t c_aux);
+int scn_conv_backward(scn_conv_t conv_t, int32_t n_slabs, int32_t ns,
+                      const float* const* dz, const int32_t* c_dz,
+                      const float* const* W, const float* aux, int32_t c_aux, int32_t act,
+                      float* dx, float* const* dW,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two Hodge shifts alone: ya = val0-operator * x, yb = val1-operator * x on group 0 of `conv`
+ * (the L_down X / L_up X products of TE:146-147 without the dense part; the SpMM GB/s metric).
+ *   x, ya, yb device [n_slabs][rows][k]; yb may be NULL for a single-operator product.               */
+int scn_spmm_dual(scn_conv_t conv, int32_t n_slabs, int32_t k,
+                  const float* x, float* ya, float* yb, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Readout (TE:151-152 with Bconds_func TE:298-303, B1_jax TE:288, nbrhoods TE:279):
+ *   logits[n,d] = sum_{e incident to v} sign(v,e) * (H[e,n,:] . w_last),  v = nbr[last[n]][d];  v = -1 -> 0
+ *   logp = logits - logsumexp_d(logits)    over ALL D entries, padding included.
+ * inc_* is B1 (optionally flipped, TE:291) as node-major CSR on device.
+ * --------------------------------------------------------------------------------------------------- */
+int scn_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
+                        const float* H, const float* w_last,
+                        const int32_t* nbr, int32_t n_nodes, int32_t max_deg,
+                        const int32_t* last_nodes,
+                        const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                        float* bh /* [N][max_deg][c]: Bcond(last) @ H, kept for the backward */,
+                        float* logits, float* logp, void* stream);
+
+/* Backward of the readout + log-softmax, fused with the last layer's activation derivative:
+ *   d_logits = d_logp - exp(logp) * sum_d d_logp
+ *   dz[e,n,:] = (sum_v sign(v,e) d_logits[n,d(v)]) * w_last * act'(H[e,n,:])    (dz fully written, zeros elsewhere)
+ *   d_w_last += sum_n sum_d d_logits[n,d] * bh[n,d,:]          (fixed summation order)               */
+int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
+                         const float* H, const float* w_last,
+                         const int32_t* nbr, int32_t n_nodes, int32_t max_deg,
+                         const int32_t* last_nodes,
+                         const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                         const int32_t* edge_nodes, /* [n_edges][2] endpoints (tail, head) */
+                         const float* bh, const float* d_logp, const float* logp, int32_t act,
+                         float* d_logits /* [N][max_deg] out */, float* dz, float* d_w_last, void* stream);
+
+/* Bunch readout (TE:198-203): logits[n,d] = nodes_out[nbr[last[n]][d]] with -1 wrapping to the last node. */
+int scn_node_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
+                             const float* nodes_out, const int32_t* nbr, int32_t max_deg,
+                             const int32_t* last_nodes, float* logits, float* logp, void* stream);
+int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
+                              const float* nodes_out, const int32_t* nbr, int32_t max_deg,
+                              const int32_t* last_nodes, const float* d_logp, const float* logp,
+                              int32_t act, float* dz, void* stream);
+
+/* Scatter ragged edge flows into a zeroed slab tensor [n_slabs][n_edges][ns][1] (the flows_in input,
+ * SDG:327-344): x[slab(n)][perm? idx][n % ns] = val.  sample_of[i] gives the trajectory of entry i. */
+int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_entries,
+                      const int32_t* sample_of, const int32_t* edge_idx, const float* val,
+                      float* x, void* stream);
+
+/* Fused Adam + ridge step on the flat parameter buffer (jax.experimental.optimizers.adam as driven by
+ * STM:300-326; ridge term of STM:54-56):   g' = g * g_scale + 2*weight_decay*w ; m,v EMA ;
+ *   w -= lr * (m / (1 - b1^(i+1))) / (sqrt(v / (1 - b2^(i+1))) + eps)                                */
+int scn_adam_step(int64_t n, float* w, const float* g, float* m, float* v,
+                  float lr, float b1, float b2, float eps, int32_t step_i,
+                  float weight_decay, float g_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCONE_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libscone_hip.so (the C-ABI declared in include/scone_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, this raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or scone_gcn_amd/csrc/build.sh.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscone_hip.so")
+
+c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+c_void_p, c_size_t = ctypes.c_void_p, ctypes.c_size_t
+P_i32 = ctypes.POINTER(c_i32)
+P_f32 = ctypes.POINTER(c_f32)
+
+SCN_MAX_GROUPS = 3
+SCN_MAX_SLOTS = 4
+ACT = {"none": 0, "tanh": 1, "relu": 2, "leaky_relu": 3}
+
+
+class GroupDesc(ctypes.Structure):
+    _fields_ = [("n_cols", c_i32), ("identity", c_i32), ("n_vals", c_i32), ("reserved", c_i32),
+                ("nnz", c_i64), ("rowptr", c_void_p), ("col", c_void_p), ("val0", c_void_p), ("val1", c_void_p)]
+
+
+# name -> (restype, argtypes); every name here must be exported by the library and declared in the header
+SIGNATURES = {
+    "scn_version": (ctypes.c_int, []),
+    "scn_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "scn_last_hip_error": (ctypes.c_char_p, []),
+    "scn_conv_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(GroupDesc), ctypes.POINTER(c_void_p)]),
+    "scn_conv_destroy": (ctypes.c_int, [c_void_p]),
+    "scn_conv_n_slots": (ctypes.c_int, [c_void_p]),
+    "scn_conv_plan_info": (ctypes.c_int, [c_void_p, P_i32, P_f32]),
+    "scn_conv_forward": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                        ctypes.POINTER(c_void_p), c_i32, c_i32, c_void_p, c_void_p]),
+    "scn_conv_backward_workspace": (c_size_t, [c_void_p, c_i32, c_i32, P_i32, c_i32]),
+    "scn_conv_backward": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                         ctypes.POINTER(c_void_p), c_void_p, c_i32, c_i32, c_void_p,
+                                         ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "scn_spmm_dual": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "scn_readout_forward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
+    "scn_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "scn_node_readout_forward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
+    "scn_node_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
+                                                 c_void_p, c_i32, c_void_p, c_void_p]),
+    "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
+                                     c_i32, c_f32, c_f32, c_void_p]),
+}
+
+_lib = None
+
+
+class SconeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises ImportError with build instructions when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run scone_gcn_amd/csrc/build.sh "
+            f"(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        lib = load()
+        msg = lib.scn_error_string(status).decode()
+        hip = lib.scn_last_hip_error().decode()
+        raise SconeHipError(f"{what} failed: {msg} (status {status})" + (f" [{hip}]" if status == -3 and hip else ""))
+
+
+def ptr_array(ptrs):
+    arr = (c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def i32_array(vals):
+    arr = (c_i32 * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+    return arr

@@ -1,0 +1,239 @@
+"""Host-side simplicial complex, shift operators and readout tables (NumPy / scipy.sparse only).
+
+Replaces the dense operator construction of the reference's data_setup (TE:240-257: L1_lower = B1^T B1,
+L1_upper = B2 B2^T, optional F L F flip, Ebli [L1, L1^2], Bunch S_00..S_22) and the readout inputs
+(TE:270-303: nbrhoods, n_nbrs, B1_jax, Bconds_func) with sparse equivalents that scale to |E| ~ 1M.
+
+Row order.  Device tensors keep each level's rows (nodes / edges / faces) in a locality order (Hilbert
+curve over the simplex centroids when coordinates are known, reverse Cuthill-McKee otherwise) so that the
+LDS-blocked kernels find a block's gather sources close together.  The permutation is internal: every
+boundary object (Shift, Bconds, flows, nbrhoods) speaks the caller's original indices.
+"""
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+from .bunch_model_matrices import compute_shift_matrices
+from .synthetic_data_gen import Complex, SparseFlows, incidence_matrices, neighborhood_table, complex_from_incidence
+
+
+def hilbert_index(x, y, order=16):
+    """Hilbert-curve index of integer grid points (vectorised)."""
+    x = np.asarray(x, np.int64).copy()
+    y = np.asarray(y, np.int64).copy()
+    d = np.zeros_like(x)
+    s = 1 << (order - 1)
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64)
+        ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, s - 1 - x, x)
+        y = np.where(flip, s - 1 - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s >>= 1
+    return d
+
+
+def _perm_from_order(order):
+    """order[new] = old  ->  perm[old] = new."""
+    perm = np.empty(len(order), np.int64)
+    perm[order] = np.arange(len(order))
+    return perm
+
+
+def _hilbert_order(pts):
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    q = ((pts - lo) / np.maximum(hi - lo, 1e-30) * 65535.0).astype(np.int64)
+    return np.argsort(hilbert_index(q[:, 0], q[:, 1]), kind="stable")
+
+
+class Layout:
+    """Row permutation of the three levels: perm[level][old] = new, order[level][new] = old."""
+
+    def __init__(self, sizes, orders=None):
+        self.sizes = tuple(int(s) for s in sizes)
+        self.order = []
+        self.perm = []
+        for lvl, n in enumerate(self.sizes):
+            o = np.arange(n, dtype=np.int64) if orders is None or orders[lvl] is None else np.asarray(orders[lvl], np.int64)
+            assert len(o) == n and np.array_equal(np.sort(o), np.arange(n))
+            self.order.append(o)
+            self.perm.append(_perm_from_order(o))
+
+    def is_identity(self, level):
+        return np.array_equal(self.order[level], np.arange(self.sizes[level]))
+
+
+class Shift:
+    """A shift operator (rows = target level, columns = source level) in the caller's index order.
+
+    Drop-in for the dense matrices the reference passes as S_lower / S_upper / S_ab (TE:137, 155, 173):
+    supports .shape, .T, @ on NumPy arrays and .toarray(); the HIP path consumes .device_csr()."""
+
+    def __init__(self, matrix, layout, row_level, col_level):
+        m = sp.csr_matrix(matrix, dtype=np.float64)
+        m.sum_duplicates()
+        m.sort_indices()
+        self.csr = m
+        self.layout = layout
+        self.row_level, self.col_level = row_level, col_level
+        assert m.shape == (layout.sizes[row_level], layout.sizes[col_level]), "shift shape does not match the complex"
+        self._T = None
+        self._dev = None
+        self._cache = {}
+
+    @property
+    def shape(self):
+        return self.csr.shape
+
+    @property
+    def T(self):
+        if self._T is None:
+            self._T = Shift(self.csr.T.tocsr(), self.layout, self.col_level, self.row_level)
+            self._T._T = self
+        return self._T
+
+    def toarray(self):
+        return self.csr.toarray()
+
+    def __matmul__(self, other):
+        return self.csr @ other
+
+    def is_symmetric(self):
+        if self.shape[0] != self.shape[1]:
+            return False
+        d = self.csr - self.csr.T
+        return d.nnz == 0 or float(abs(d).max()) == 0.0
+
+    def device_csr(self):
+        """P_row M P_col^T with sorted column indices: the operator in device row order."""
+        if self._dev is None:
+            coo = self.csr.tocoo()
+            r = self.layout.perm[self.row_level][coo.row]
+            c = self.layout.perm[self.col_level][coo.col]
+            m = sp.csr_matrix((coo.data, (r, c)), shape=self.shape)
+            m.sort_indices()
+            self._dev = m
+        return self._dev
+
+
+def union_pattern(mats):
+    """Shared CSR pattern of several same-shaped matrices and each one's values on it (zeros where absent)."""
+    shape = mats[0].shape
+    ncols = shape[1]
+    keys = []
+    for m in mats:
+        coo = m.tocoo()
+        keys.append(coo.row.astype(np.int64) * ncols + coo.col.astype(np.int64))
+    ukeys = np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
+    rows = (ukeys // ncols).astype(np.int64)
+    cols = (ukeys % ncols).astype(np.int32)
+    rowptr = np.zeros(shape[0] + 1, np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    vals = []
+    for m, k in zip(mats, keys):
+        coo = m.tocoo()
+        v = np.zeros(len(ukeys), np.float32)
+        v[np.searchsorted(ukeys, k)] = coo.data.astype(np.float32)
+        vals.append(v)
+    return rowptr, cols, vals
+
+
+class Bconds:
+    """The readout operand: callable like the reference's Bconds_func(n) = B1_jax[nbrhoods[n]] (TE:298-303) and
+    carrier of the sparse tables the HIP readout uses (node-major incidence CSR, padded neighbour table)."""
+
+    def __init__(self, cx, layout, nbrhoods, flips=None):
+        self.cx, self.layout = cx, layout
+        self.nbrhoods = nbrhoods                              # (V, D) original node ids, -1 padded
+        self.flips = None if flips is None else np.asarray(flips, np.float64)
+        self._dev = {}
+
+    def __call__(self, n):
+        B1, _ = incidence_matrices(self.cx)
+        if self.flips is not None:
+            B1 = B1 @ sp.diags(self.flips)                    # TE:291
+        B1 = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()   # zero row for index -1 (TE:288)
+        return B1[np.asarray(self.nbrhoods[n])].toarray()
+
+    def incidence_tables(self):
+        """Node-major CSR of (flipped) B1 with edges in DEVICE order; endpoints per device edge."""
+        E = self.cx.n_edges
+        pe = self.layout.perm[1]
+        tail, head = self.cx.edges[:, 0], self.cx.edges[:, 1]
+        f = np.ones(E) if self.flips is None else self.flips
+        node = np.concatenate([tail, head])
+        edge = np.concatenate([pe, pe])
+        sign = np.concatenate([-f, f])
+        order = np.lexsort((edge, node))
+        node, edge, sign = node[order], edge[order], sign[order]
+        ptr = np.zeros(self.cx.n_nodes + 1, np.int64)
+        np.add.at(ptr, node + 1, 1)
+        edge_nodes = np.zeros((E, 2), np.int32)
+        edge_nodes[pe, 0] = tail
+        edge_nodes[pe, 1] = head
+        return np.cumsum(ptr).astype(np.int32), edge.astype(np.int32), sign.astype(np.float32), edge_nodes
+
+
+class SimplicialComplex:
+    """Complex + layout + operator factory.  Build from arrays, from a Complex, or from B1/B2 (dense or sparse)."""
+
+    def __init__(self, cx, reorder=True):
+        self.cx = cx
+        self.B1, self.B2 = incidence_matrices(cx)
+        self.nbrhoods, self.degrees = neighborhood_table(cx)
+        self.max_degree = int(self.nbrhoods.shape[1])
+        orders = [None, None, None]
+        if reorder and cx.n_edges > 1:
+            if cx.coords is not None:
+                mid = 0.5 * (cx.coords[cx.edges[:, 0]] + cx.coords[cx.edges[:, 1]])
+                orders[1] = _hilbert_order(mid)
+            else:
+                L = (self.B1.T @ self.B1).tocsr()
+                orders[1] = np.asarray(reverse_cuthill_mckee(L, symmetric_mode=True), np.int64)
+        self.layout = Layout((cx.n_nodes, cx.n_edges, cx.n_faces), orders)
+
+    @classmethod
+    def from_incidence(cls, B1, B2, coords=None, reorder=True):
+        edges, faces = complex_from_incidence(B1, B2)
+        order = np.lexsort((edges[:, 1], edges[:, 0]))
+        if not np.array_equal(order, np.arange(len(order))):
+            raise ValueError("B1 columns must list edges in sorted (tail, head) order, as the reference writes them")
+        return cls(Complex(n_nodes=sp.csr_matrix(B1).shape[0], edges=edges, faces=faces, coords=coords), reorder=reorder)
+
+    # ---- operators (TE:240-257) ----
+    def flip_vector(self, seed=1):
+        """flips ~ choice([1,-1], p=[.8,.2]) under seed 1 (TE:216-219)."""
+        rs = np.random.RandomState(seed)
+        return rs.choice([1, -1], size=self.cx.n_edges, replace=True, p=[0.8, 0.2]).astype(np.float64)
+
+    def hodge_laplacians(self, flips=None):
+        L_lo = (self.B1.T @ self.B1).tocsr()
+        L_up = (self.B2 @ self.B2.T).tocsr()
+        if flips is not None:
+            F = sp.diags(flips)
+            L_lo, L_up = (F @ L_lo @ F).tocsr(), (F @ L_up @ F).tocsr()        # TE:242-244
+        return L_lo, L_up
+
+    def scone_shifts(self, flips=None):
+        L_lo, L_up = self.hodge_laplacians(flips)
+        return [Shift(L_lo, self.layout, 1, 1), Shift(L_up, self.layout, 1, 1)]   # TE:247-248
+
+    def ebli_shifts(self, flips=None):
+        L_lo, L_up = self.hodge_laplacians(flips)
+        L1 = (L_lo + L_up).tocsr()
+        return [Shift(L1, self.layout, 1, 1), Shift((L1 @ L1).tocsr(), self.layout, 1, 1)]   # TE:251-253
+
+    def bunch_shifts(self):
+        S = compute_shift_matrices(self.B1, self.B2)                                           # TE:255-257
+        lv = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2)]   # (row level, col level) of S_00,S_10,S_01,S_11,S_21,S_12,S_22
+        return [Shift(m, self.layout, r, c) for m, (r, c) in zip(S, lv)]
+
+    def bconds(self, flips=None):
+        return Bconds(self.cx, self.layout, self.nbrhoods, flips)
+
+    def n_nbrs(self, last_nodes):
+        return self.degrees[np.asarray(last_nodes)]                                          # TE:276

@@ -1,0 +1,459 @@
+// Shift-convolution operator objects and the GENERIC kernels (any channel width, any number of groups).
+// The LDS-blocked MFMA kernels for the scone/ebli hot configurations live in scn_blocked.hip and are
+// dispatched from here when the shape qualifies.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "scn_internal.h"
+
+namespace scn {
+
+static thread_local std::string g_hip_err;
+void set_hip_error(hipError_t e, const char* where) {
+    g_hip_err = std::string(where) + ": " + hipGetErrorString(e);
+}
+
+// implemented in scn_blocked.hip
+int build_block_plan(scn_conv_s* c);
+void free_block_plan(scn_conv_s* c);
+bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in, int c_out);
+int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
+                    const float* const* W, int c_out, int act, float* out, hipStream_t st);
+bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz, int c_aux, bool has_dx);
+size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux);
+int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
+                     const float* const* W, const float* aux, int c_aux, int act, float* dx,
+                     float* const* dW, void* ws, size_t ws_bytes, hipStream_t st);
+bool blocked_spmm_supported(const scn_conv_s* c, int k);
+int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// generic kernels
+// ------------------------------------------------------------------------------------------------
+struct OpArrays {
+    int32_t n_rows, n_groups, n_slots;
+    const int32_t* rowptr[SCN_MAX_GROUPS];
+    const int32_t* col[SCN_MAX_GROUPS];
+    const float* val0[SCN_MAX_GROUPS];
+    const float* val1[SCN_MAX_GROUPS];
+    int32_t identity[SCN_MAX_GROUPS], n_vals[SCN_MAX_GROUPS], n_cols[SCN_MAX_GROUPS];
+    int32_t slot_base[SCN_MAX_GROUPS], g_slots[SCN_MAX_GROUPS];
+};
+
+struct FwdArgs {
+    OpArrays op;
+    int32_t n_slabs, ns, c_out, act;
+    int32_t c_in[SCN_MAX_GROUPS];
+    const float* src[SCN_MAX_GROUPS];
+    const float* W[SCN_MAX_SLOTS];
+    float* out;
+};
+
+// gather every slot of every group for (row r, slab s) into LDS: Z[slot][ns*c_g]
+template <typename ArgsT>
+__device__ __forceinline__ void gather_row(const ArgsT& a, const float* const* srcs, const int32_t* cw,
+                                           int r, int s, float* Z) {
+    int zoff = 0;
+    for (int g = 0; g < a.op.n_groups; ++g) {
+        const int K = a.ns * cw[g];
+        const float* X = srcs[g] + (size_t)s * a.op.n_cols[g] * K;
+        const int j0 = a.op.rowptr[g][r], j1 = a.op.rowptr[g][r + 1];
+        const int nv = a.op.n_vals[g], idn = a.op.identity[g];
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int j = j0; j < j1; ++j) {
+                const float x = X[(size_t)a.op.col[g][j] * K + k];
+                if (nv > 0) a0 = fmaf(a.op.val0[g][j], x, a0);
+                if (nv > 1) a1 = fmaf(a.op.val1[g][j], x, a1);
+            }
+            int sl = 0;
+            if (idn) Z[zoff + (sl++) * K + k] = X[(size_t)r * K + k];
+            if (nv > 0) Z[zoff + (sl++) * K + k] = a0;
+            if (nv > 1) Z[zoff + (sl++) * K + k] = a1;
+        }
+        zoff += a.op.g_slots[g] * K;
+    }
+}
+
+__global__ __launch_bounds__(128) void conv_fwd_generic(FwdArgs a) {
+    extern __shared__ float Z[];
+    const int r = blockIdx.x, s = blockIdx.y;
+    gather_row(a, a.src, a.c_in, r, s, Z);
+    __syncthreads();
+    const int KO = a.ns * a.c_out;
+    for (int o = threadIdx.x; o < KO; o += blockDim.x) {
+        const int n = o / a.c_out, co = o - n * a.c_out;
+        float acc = 0.f;
+        int zoff = 0;
+        for (int g = 0; g < a.op.n_groups; ++g) {
+            const int cg = a.c_in[g], K = a.ns * cg;
+            for (int sl = 0; sl < a.op.g_slots[g]; ++sl) {
+                const float* Wp = a.W[a.op.slot_base[g] + sl];
+                const float* z = Z + zoff + sl * K + n * cg;
+                for (int ci = 0; ci < cg; ++ci) acc = fmaf(z[ci], Wp[ci * a.c_out + co], acc);
+            }
+            zoff += a.op.g_slots[g] * K;
+        }
+        a.out[((size_t)(s * (size_t)a.op.n_rows + r) * a.ns) * a.c_out + o] = act_apply(a.act, acc);
+    }
+}
+
+constexpr int BWD_THREADS = 256;
+constexpr int BWD_MAXP = 48;   // dW pairs per thread: c_aux * sum(c_dz over slots) <= 256 * 48
+
+struct BwdArgs {
+    OpArrays op;
+    int32_t n_slabs, ns, c_aux, act;
+    int32_t c_dz[SCN_MAX_GROUPS];
+    const float* dz[SCN_MAX_GROUPS];
+    const float* W[SCN_MAX_SLOTS];
+    const float* aux;
+    float* dx;
+    float* partial;          // [gridDim.x][total_pairs]
+    int32_t total_cols;      // sum over slots of c_dz(group of slot)
+    int32_t total_pairs;     // c_aux * total_cols
+    int64_t n_items;         // n_rows * n_slabs
+};
+
+__global__ __launch_bounds__(BWD_THREADS) void conv_bwd_generic(BwdArgs a) {
+    extern __shared__ float sm[];
+    // LDS: G [sum_slots ns*c] | AUX [ns*c_aux]
+    int gtot = 0;
+    for (int g = 0; g < a.op.n_groups; ++g) gtot += a.op.g_slots[g] * a.ns * a.c_dz[g];
+    float* G = sm;
+    float* AUX = sm + gtot;
+
+    // per-thread dW pair bookkeeping: pair p = ca * total_cols + col ; col -> (slot, c)
+    float accW[BWD_MAXP];
+    int pz[BWD_MAXP];    // LDS offset of G[slot][n=0][c]
+    int pstride[BWD_MAXP];
+    int pca[BWD_MAXP];
+#pragma unroll
+    for (int i = 0; i < BWD_MAXP; ++i) {
+        accW[i] = 0.f;
+        pz[i] = 0; pstride[i] = 0; pca[i] = 0;
+        const int p = threadIdx.x + i * BWD_THREADS;
+        if (p < a.total_pairs) {
+            const int ca = p / a.total_cols;
+            int colc = p - ca * a.total_cols;
+            int zoff = 0;
+            for (int g = 0; g < a.op.n_groups; ++g) {
+                const int cg = a.c_dz[g], K = a.ns * cg;
+                bool found = false;
+                for (int sl = 0; sl < a.op.g_slots[g]; ++sl) {
+                    if (!found && colc < cg) { pz[i] = zoff + sl * K + colc; pstride[i] = cg; found = true; }
+                    if (!found) colc -= cg;
+                }
+                if (found) break;
+                zoff += a.op.g_slots[g] * K;
+            }
+            pca[i] = ca;
+        }
+    }
+
+    for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int s = (int)(item / a.op.n_rows);
+        const int r = (int)(item - (int64_t)s * a.op.n_rows);
+        gather_row(a, a.dz, a.c_dz, r, s, G);
+        const size_t abase = ((size_t)s * a.op.n_rows + r) * a.ns * a.c_aux;
+        for (int k = threadIdx.x; k < a.ns * a.c_aux; k += blockDim.x) AUX[k] = a.aux[abase + k];
+        __syncthreads();
+        if (a.dx) {
+            for (int o = threadIdx.x; o < a.ns * a.c_aux; o += blockDim.x) {
+                const int n = o / a.c_aux, ca = o - n * a.c_aux;
+                float acc = 0.f;
+                int zoff = 0;
+                for (int g = 0; g < a.op.n_groups; ++g) {
+                    const int cg = a.c_dz[g], K = a.ns * cg;
+                    for (int sl = 0; sl < a.op.g_slots[g]; ++sl) {
+                        const float* Wp = a.W[a.op.slot_base[g] + sl] + (size_t)ca * cg;
+                        const float* z = G + zoff + sl * K + n * cg;
+                        for (int c = 0; c < cg; ++c) acc = fmaf(z[c], Wp[c], acc);
+                    }
+                    zoff += a.op.g_slots[g] * K;
+                }
+                a.dx[abase + o] = acc * act_grad_from_output(a.act, AUX[o]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BWD_MAXP; ++i) {
+            if (threadIdx.x + i * BWD_THREADS < a.total_pairs) {
+                float acc = accW[i];
+                for (int n = 0; n < a.ns; ++n)
+                    acc = fmaf(AUX[n * a.c_aux + pca[i]], G[pz[i] + n * pstride[i]], acc);
+                accW[i] = acc;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < BWD_MAXP; ++i) {
+        const int p = threadIdx.x + i * BWD_THREADS;
+        if (p < a.total_pairs) a.partial[(size_t)blockIdx.x * a.total_pairs + p] = accW[i];
+    }
+}
+
+struct ReduceArgs {
+    const float* partial;
+    int32_t n_partials, total_pairs, total_cols, n_slots;
+    int32_t slot_c[SCN_MAX_SLOTS];   // c_dz of each slot
+    float* dW[SCN_MAX_SLOTS];
+};
+
+// dW_slot[ca][c] += sum_b partial[b][ca*total_cols + col]   (fixed order -> bitwise reproducible)
+__global__ void dw_reduce_kernel(ReduceArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.total_pairs) return;
+    float acc = 0.f;
+    for (int b = 0; b < a.n_partials; ++b) acc += a.partial[(size_t)b * a.total_pairs + p];
+    const int ca = p / a.total_cols;
+    int col = p - ca * a.total_cols;
+    for (int sl = 0; sl < a.n_slots; ++sl) {
+        if (col < a.slot_c[sl]) {
+            if (a.dW[sl]) a.dW[sl][ca * a.slot_c[sl] + col] += acc;
+            return;
+        }
+        col -= a.slot_c[sl];
+    }
+}
+
+// generic dual SpMM: one block per (row, slab)
+__global__ __launch_bounds__(128) void spmm_dual_generic(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const float* __restrict__ v0,
+                                                         const float* __restrict__ v1,
+                                                         int n_rows, int n_cols, int k,
+                                                         const float* __restrict__ x,
+                                                         float* __restrict__ ya, float* __restrict__ yb) {
+    const int r = blockIdx.x, s = blockIdx.y;
+    const float* X = x + (size_t)s * n_cols * k;
+    const int j0 = rowptr[r], j1 = rowptr[r + 1];
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int j = j0; j < j1; ++j) {
+            const float xv = X[(size_t)col[j] * k + t];
+            a0 = fmaf(v0[j], xv, a0);
+            if (yb) a1 = fmaf(v1[j], xv, a1);
+        }
+        const size_t o = ((size_t)s * n_rows + r) * k + t;
+        ya[o] = a0;
+        if (yb) yb[o] = a1;
+    }
+}
+
+static void fill_op(const scn_conv_s* c, OpArrays& op) {
+    op.n_rows = c->n_rows; op.n_groups = c->n_groups; op.n_slots = c->n_slots;
+    for (int g = 0; g < SCN_MAX_GROUPS; ++g) {
+        const Group& G = c->g[g];
+        op.rowptr[g] = G.d_rowptr; op.col[g] = G.d_col; op.val0[g] = G.d_val0; op.val1[g] = G.d_val1;
+        op.identity[g] = G.identity; op.n_vals[g] = G.n_vals; op.n_cols[g] = G.n_cols;
+        op.slot_base[g] = G.slot_base; op.g_slots[g] = G.n_slots;
+    }
+}
+
+}  // namespace scn
+
+using namespace scn;
+
+extern "C" {
+
+int scn_version(void) { return 100; }
+
+const char* scn_error_string(int status) {
+    switch (status) {
+        case SCN_OK: return "ok";
+        case SCN_ERR_BAD_ARG: return "bad argument";
+        case SCN_ERR_BAD_SHAPE: return "bad shape";
+        case SCN_ERR_HIP: return "HIP runtime error (see scn_last_hip_error)";
+        case SCN_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SCN_ERR_NOMEM: return "out of memory";
+        case SCN_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+const char* scn_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int scn_conv_destroy(scn_conv_t c) {
+    if (!c) return SCN_OK;
+    for (int g = 0; g < SCN_MAX_GROUPS; ++g) {
+        if (c->g[g].d_rowptr) (void)hipFree(c->g[g].d_rowptr);
+        if (c->g[g].d_col) (void)hipFree(c->g[g].d_col);
+        if (c->g[g].d_val0) (void)hipFree(c->g[g].d_val0);
+        if (c->g[g].d_val1) (void)hipFree(c->g[g].d_val1);
+    }
+    free_block_plan(c);
+    delete c;
+    return SCN_OK;
+}
+
+int scn_conv_create(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups, scn_conv_t* out) {
+    if (!out || !groups || n_rows <= 0 || n_groups <= 0 || n_groups > SCN_MAX_GROUPS) return SCN_ERR_BAD_ARG;
+    *out = nullptr;
+    scn_conv_s* c = new (std::nothrow) scn_conv_s();
+    if (!c) return SCN_ERR_NOMEM;
+    c->n_rows = n_rows;
+    c->n_groups = n_groups;
+    int slot = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const scn_group_desc& d = groups[g];
+        if (d.n_cols <= 0 || d.n_vals < 0 || d.n_vals > 2 || d.nnz < 0 || (d.identity && d.n_cols != n_rows) ||
+            (d.n_vals == 0 && !d.identity) || !d.rowptr || (d.nnz > 0 && !d.col) ||
+            (d.n_vals > 0 && d.nnz > 0 && !d.val0) || (d.n_vals > 1 && d.nnz > 0 && !d.val1)) {
+            delete c;
+            return SCN_ERR_BAD_ARG;
+        }
+        if (d.rowptr[0] != 0 || d.rowptr[n_rows] != d.nnz) { delete c; return SCN_ERR_BAD_SHAPE; }
+        for (int r = 0; r < n_rows; ++r)
+            if (d.rowptr[r + 1] < d.rowptr[r]) { delete c; return SCN_ERR_BAD_SHAPE; }
+        for (int64_t j = 0; j < d.nnz; ++j)
+            if (d.col[j] < 0 || d.col[j] >= d.n_cols) { delete c; return SCN_ERR_BAD_SHAPE; }
+        Group& G = c->g[g];
+        G.n_cols = d.n_cols; G.identity = d.identity ? 1 : 0; G.n_vals = d.n_vals; G.nnz = d.nnz;
+        G.slot_base = slot;
+        G.n_slots = G.identity + G.n_vals;
+        if (slot + G.n_slots > SCN_MAX_SLOTS) { delete c; return SCN_ERR_UNSUPPORTED; }
+        if (G.identity) { c->slot_group[slot] = g; c->slot_kind[slot++] = 0; }
+        if (G.n_vals > 0) { c->slot_group[slot] = g; c->slot_kind[slot++] = 1; }
+        if (G.n_vals > 1) { c->slot_group[slot] = g; c->slot_kind[slot++] = 2; }
+        try {
+            G.h_rowptr.assign(d.rowptr, d.rowptr + n_rows + 1);
+            G.h_col.assign(d.col, d.col + d.nnz);
+            if (G.n_vals > 0) G.h_val0.assign(d.val0, d.val0 + d.nnz);
+            if (G.n_vals > 1) G.h_val1.assign(d.val1, d.val1 + d.nnz);
+        } catch (...) { delete c; return SCN_ERR_NOMEM; }
+    }
+    c->n_slots = slot;
+    for (int g = 0; g < n_groups; ++g) {
+        Group& G = c->g[g];
+        const size_t nz = (size_t)std::max<int64_t>(G.nnz, 1);
+#define SCN_CREATE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_hip_error(_e, #expr); scn_conv_destroy(c); return SCN_ERR_HIP; } } while (0)
+        SCN_CREATE_TRY(hipMalloc(&G.d_rowptr, sizeof(int32_t) * (n_rows + 1)));
+        SCN_CREATE_TRY(hipMemcpy(G.d_rowptr, G.h_rowptr.data(), sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
+        SCN_CREATE_TRY(hipMalloc(&G.d_col, sizeof(int32_t) * nz));
+        if (G.nnz) SCN_CREATE_TRY(hipMemcpy(G.d_col, G.h_col.data(), sizeof(int32_t) * G.nnz, hipMemcpyHostToDevice));
+        if (G.n_vals > 0) {
+            SCN_CREATE_TRY(hipMalloc(&G.d_val0, sizeof(float) * nz));
+            if (G.nnz) SCN_CREATE_TRY(hipMemcpy(G.d_val0, G.h_val0.data(), sizeof(float) * G.nnz, hipMemcpyHostToDevice));
+        }
+        if (G.n_vals > 1) {
+            SCN_CREATE_TRY(hipMalloc(&G.d_val1, sizeof(float) * nz));
+            if (G.nnz) SCN_CREATE_TRY(hipMemcpy(G.d_val1, G.h_val1.data(), sizeof(float) * G.nnz, hipMemcpyHostToDevice));
+        }
+    }
+    int st = build_block_plan(c);
+    if (st != SCN_OK) { scn_conv_destroy(c); return st; }
+    *out = c;
+    return SCN_OK;
+}
+
+int scn_conv_n_slots(scn_conv_t c) { return c ? c->n_slots : SCN_ERR_BAD_ARG; }
+
+int scn_conv_plan_info(scn_conv_t c, int32_t* n_blocks, float* mean_sources_per_row) {
+    if (!c) return SCN_ERR_BAD_ARG;
+    if (n_blocks) *n_blocks = c->plan.built ? c->plan.n_blocks : 0;
+    if (mean_sources_per_row) *mean_sources_per_row = c->plan.built ? (float)c->plan.mean_src_per_row : 0.f;
+    return SCN_OK;
+}
+
+int scn_conv_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
+                     const float* const* W, int32_t c_out, int32_t act, float* out, void* stream) {
+    if (!c || !src || !c_in || !W || !out) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || c_out <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
+    for (int g = 0; g < c->n_groups; ++g)
+        if (!src[g] || c_in[g] <= 0) return SCN_ERR_BAD_ARG;
+    for (int s = 0; s < c->n_slots; ++s)
+        if (!W[s]) return SCN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (blocked_forward_supported(c, ns, c_in, c_out))
+        return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, st);
+    FwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_op(c, a.op);
+    a.n_slabs = n_slabs; a.ns = ns; a.c_out = c_out; a.act = act; a.out = out;
+    size_t lds = 0;
+    for (int g = 0; g < c->n_groups; ++g) {
+        a.c_in[g] = c_in[g]; a.src[g] = src[g];
+        lds += (size_t)c->g[g].n_slots * ns * c_in[g] * sizeof(float);
+    }
+    for (int s = 0; s < c->n_slots; ++s) a.W[s] = W[s];
+    if (lds > 64 * 1024) return SCN_ERR_UNSUPPORTED;
+    dim3 grid(c->n_rows, n_slabs);
+    hipLaunchKernelGGL(conv_fwd_generic, grid, dim3(128), lds, st, a);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+static int generic_bwd_blocks(const scn_conv_s* c, int n_slabs) {
+    int64_t items = (int64_t)c->n_rows * n_slabs;
+    return (int)std::min<int64_t>(items, 2048);
+}
+
+size_t scn_conv_backward_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, const int32_t* c_dz, int32_t c_aux) {
+    if (!c || !c_dz || n_slabs <= 0 || ns <= 0 || c_aux <= 0) return 0;
+    size_t cols = 0;
+    for (int s = 0; s < c->n_slots; ++s) cols += c_dz[c->slot_group[s]];
+    size_t generic = (size_t)generic_bwd_blocks(c, n_slabs) * cols * c_aux * sizeof(float);
+    size_t blocked = blocked_backward_workspace(c, n_slabs, ns, c_dz, c_aux);
+    return std::max(generic, blocked) + 256;
+}
+
+int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,
+                      const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
+                      float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !dz || !c_dz || !W || !aux || !dW || !workspace) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || c_aux <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    for (int g = 0; g < c->n_groups; ++g)
+        if (!dz[g] || c_dz[g] <= 0) return SCN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace_bytes < scn_conv_backward_workspace(c, n_slabs, ns, c_dz, c_aux)) return SCN_ERR_WORKSPACE;
+    if (blocked_backward_supported(c, ns, c_dz, c_aux, dx != nullptr))
+        return blocked_backward(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes, st);
+
+    BwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_op(c, a.op);
+    a.n_slabs = n_slabs; a.ns = ns; a.c_aux = c_aux; a.act = act; a.aux = aux; a.dx = dx;
+    a.partial = (float*)workspace;
+    size_t lds = (size_t)ns * c_aux * sizeof(float);
+    for (int g = 0; g < c->n_groups; ++g) {
+        a.c_dz[g] = c_dz[g]; a.dz[g] = dz[g];
+        lds += (size_t)c->g[g].n_slots * ns * c_dz[g] * sizeof(float);
+    }
+    int cols = 0;
+    for (int s = 0; s < c->n_slots; ++s) { a.W[s] = W[s]; cols += c_dz[c->slot_group[s]]; }
+    a.total_cols = cols;
+    a.total_pairs = cols * c_aux;
+    a.n_items = (int64_t)c->n_rows * n_slabs;
+    if (a.total_pairs > BWD_THREADS * BWD_MAXP || lds > 64 * 1024) return SCN_ERR_UNSUPPORTED;
+    for (int s = 0; s < c->n_slots; ++s)
+        if (dx && !W[s]) return SCN_ERR_BAD_ARG;
+    const int nb = generic_bwd_blocks(c, n_slabs);
+    hipLaunchKernelGGL(conv_bwd_generic, dim3(nb), dim3(BWD_THREADS), lds, st, a);
+    SCN_LAUNCH_CHECK();
+    ReduceArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.partial = a.partial; ra.n_partials = nb; ra.total_pairs = a.total_pairs; ra.total_cols = cols;
+    ra.n_slots = c->n_slots;
+    for (int s = 0; s < c->n_slots; ++s) { ra.slot_c[s] = c_dz[c->slot_group[s]]; ra.dW[s] = dW[s]; }
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((a.total_pairs + 255) / 256), dim3(256), 0, st, ra);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_spmm_dual(scn_conv_t c, int32_t n_slabs, int32_t k, const float* x, float* ya, float* yb, void* stream) {
+    if (!c || !x || !ya) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || k <= 0 || n_slabs > 65535) return SCN_ERR_BAD_SHAPE;
+    const Group& G = c->g[0];
+    if (G.n_vals < 1 || (yb && G.n_vals < 2)) return SCN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (blocked_spmm_supported(c, k)) return blocked_spmm(c, n_slabs, k, x, ya, yb, st);
+    hipLaunchKernelGGL(spmm_dual_generic, dim3(c->n_rows, n_slabs), dim3(128), 0, st,
+                       G.d_rowptr, G.d_col, G.d_val0, G.d_val1, c->n_rows, G.n_cols, k, x, ya, yb);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+}  // extern "C"

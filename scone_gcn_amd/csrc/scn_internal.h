@@ -1,0 +1,90 @@
+// Internal declarations shared by the translation units of libscone_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "scone_hip.h"
+
+namespace scn {
+
+void set_hip_error(hipError_t e, const char* where);
+
+#define SCN_HIP_TRY(expr)                                   \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) {                             \
+            ::scn::set_hip_error(_e, #expr);                \
+            return SCN_ERR_HIP;                             \
+        }                                                   \
+    } while (0)
+
+#define SCN_LAUNCH_CHECK()                                  \
+    do {                                                    \
+        hipError_t _e = hipGetLastError();                  \
+        if (_e != hipSuccess) {                             \
+            ::scn::set_hip_error(_e, "kernel launch");      \
+            return SCN_ERR_HIP;                             \
+        }                                                   \
+    } while (0)
+
+// activation and its derivative expressed through the OUTPUT value y (what the backward has at hand)
+__device__ __forceinline__ float act_apply(int act, float z) {
+    switch (act) {
+        case SCN_ACT_TANH: return tanhf(z);
+        case SCN_ACT_RELU: return fmaxf(z, 0.f);
+        case SCN_ACT_LEAKY_RELU: return z >= 0.f ? z : 0.01f * z;
+        default: return z;
+    }
+}
+__device__ __forceinline__ float act_grad_from_output(int act, float y) {
+    switch (act) {
+        case SCN_ACT_TANH: return 1.f - y * y;
+        case SCN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SCN_ACT_LEAKY_RELU: return y >= 0.f ? 1.f : 0.01f;
+        default: return 1.f;
+    }
+}
+
+struct Group {
+    int32_t n_cols = 0, identity = 0, n_vals = 0;
+    int64_t nnz = 0;
+    int32_t slot_base = 0, n_slots = 0;
+    // device copies
+    int32_t* d_rowptr = nullptr;
+    int32_t* d_col = nullptr;
+    float* d_val0 = nullptr;
+    float* d_val1 = nullptr;
+    // host copies (plan building)
+    std::vector<int32_t> h_rowptr, h_col;
+    std::vector<float> h_val0, h_val1;
+};
+
+// LDS-blocked execution plan of a single-group operator (see scn_blocked.hip)
+struct BlockPlan {
+    bool built = false;
+    int32_t n_blocks = 0;
+    int32_t max_rows = 0;      // rows per block upper bound (R)
+    int32_t max_src = 0;       // staged source pieces per block upper bound
+    int32_t ell_width = 0;     // padded entries per row
+    double mean_src_per_row = 0.0;
+    int32_t* d_blk_row0 = nullptr;   // [n_blocks+1]
+    int32_t* d_src_ptr = nullptr;    // [n_blocks+1]
+    int32_t* d_src_rows = nullptr;   // [src_ptr[n_blocks]] global source row ids, ascending within a block
+    // ELL entries, per block [ell_width][max_rows]: local slot (uint16 in low bits) and two values
+    uint16_t* d_ell_slot = nullptr;
+    float* d_ell_v0 = nullptr;
+    float* d_ell_v1 = nullptr;
+    uint16_t* d_self_slot = nullptr; // [n_blocks][max_rows] slot of the row itself (identity term), 0xFFFF if absent
+};
+
+}  // namespace scn
+
+struct scn_conv_s {
+    int32_t n_rows = 0, n_groups = 0, n_slots = 0;
+    scn::Group g[SCN_MAX_GROUPS];
+    int32_t slot_group[SCN_MAX_SLOTS] = {0, 0, 0, 0};
+    int32_t slot_kind[SCN_MAX_SLOTS] = {0, 0, 0, 0};   // 0 identity, 1 val0, 2 val1
+    scn::BlockPlan plan;
+};

@@ -1,0 +1,285 @@
+// Readout (+ log-softmax), its backward, flow scatter and the fused Adam/ridge step.
+#include <cstring>
+
+#include "scn_internal.h"
+
+namespace scn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+constexpr int RO_MAXD = 64;   // max neighbourhood width handled by one wave (lane d)
+
+// one wave per trajectory
+__global__ __launch_bounds__(64) void readout_fwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+                                                         const float* __restrict__ w, const int32_t* __restrict__ nbr,
+                                                         int max_deg, const int32_t* __restrict__ last_nodes,
+                                                         const int32_t* __restrict__ inc_ptr,
+                                                         const int32_t* __restrict__ inc_edge,
+                                                         const float* __restrict__ inc_sign,
+                                                         float* __restrict__ bh, float* __restrict__ logits,
+                                                         float* __restrict__ logp) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    float my_logit = 0.f;   // lane d keeps logit d
+    for (int d = 0; d < max_deg; ++d) {
+        const int v = nbr[(size_t)vlast * max_deg + d];
+        float lg = 0.f;
+        for (int c0 = 0; c0 < c; c0 += 64) {
+            const int cc = c0 + lane;
+            float acc = 0.f;
+            if (v >= 0 && cc < c) {
+                for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
+                    const int e = inc_edge[j];
+                    acc = fmaf(inc_sign[j], H[(((size_t)s * n_edges + e) * ns + i) * c + cc], acc);
+                }
+            }
+            if (cc < c) {
+                bh[((size_t)n * max_deg + d) * c + cc] = acc;
+                lg = fmaf(acc, w[cc], lg);
+            }
+        }
+        lg = wave_sum(lg);
+        if (lane == d) my_logit = lg;
+    }
+    const float x = lane < max_deg ? my_logit : -INFINITY;
+    const float m = wave_max(x);
+    const float se = wave_sum(lane < max_deg ? expf(x - m) : 0.f);
+    const float lse = m + logf(se);
+    if (lane < max_deg) {
+        logits[(size_t)n * max_deg + lane] = my_logit;
+        logp[(size_t)n * max_deg + lane] = my_logit - lse;
+    }
+}
+
+__global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+                                                         const float* __restrict__ w, const int32_t* __restrict__ nbr,
+                                                         int max_deg, const int32_t* __restrict__ last_nodes,
+                                                         const int32_t* __restrict__ inc_ptr,
+                                                         const int32_t* __restrict__ inc_edge,
+                                                         const float* __restrict__ inc_sign,
+                                                         const int32_t* __restrict__ edge_nodes,
+                                                         const float* __restrict__ d_logp,
+                                                         const float* __restrict__ logp, int act,
+                                                         float* __restrict__ dz, float* __restrict__ dl_out) {
+    __shared__ float dl[RO_MAXD];
+    __shared__ int nb[RO_MAXD];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    const float g = lane < max_deg ? d_logp[(size_t)n * max_deg + lane] : 0.f;
+    const float gs = wave_sum(g);
+    if (lane < max_deg) {
+        const float v = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
+        dl[lane] = v;
+        dl_out[(size_t)n * max_deg + lane] = v;
+        nb[lane] = nbr[(size_t)vlast * max_deg + lane];
+    }
+    __syncthreads();
+    for (int d = 0; d < max_deg; ++d) {
+        const int v = nb[d];
+        if (v < 0) continue;
+        for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
+            const int e = inc_edge[j];
+            const int t = edge_nodes[2 * e], h = edge_nodes[2 * e + 1];
+            const int other = (t == v) ? h : t;
+            int dk = -1;
+            for (int q = 0; q < max_deg; ++q)
+                if (nb[q] == other) dk = q;
+            if (dk >= 0 && other < v) continue;          // handled from the other endpoint's side
+            // the two endpoints carry opposite incidence signs (B1[tail]=-1, B1[head]=+1; a flip scales both)
+            const float coef = inc_sign[j] * (dl[d] - (dk >= 0 ? dl[dk] : 0.f));
+            const size_t base = (((size_t)s * n_edges + e) * ns + i) * c;
+            for (int cc = lane; cc < c; cc += 64)
+                dz[base + cc] = coef * w[cc] * act_grad_from_output(act, H[base + cc]);
+        }
+    }
+}
+
+// d_w[c] += sum_{n,d} dl[n,d] * bh[n,d,c] in a fixed order
+__global__ void readout_dw_kernel(int nd, int c, const float* __restrict__ dl, const float* __restrict__ bh,
+                                  float* __restrict__ d_w) {
+    const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cc >= c) return;
+    float acc = 0.f;
+    for (int q = 0; q < nd; ++q) acc = fmaf(dl[q], bh[(size_t)q * c + cc], acc);
+    d_w[cc] += acc;
+}
+
+__global__ __launch_bounds__(64) void node_readout_fwd_kernel(int ns, int n_nodes, const float* __restrict__ X,
+                                                              const int32_t* __restrict__ nbr, int max_deg,
+                                                              const int32_t* __restrict__ last_nodes,
+                                                              float* __restrict__ logits, float* __restrict__ logp) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    float x = -INFINITY, lg = 0.f;
+    if (lane < max_deg) {
+        int v = nbr[(size_t)vlast * max_deg + lane];
+        if (v < 0) v += n_nodes;                      // index -1 wraps to the last node (TE:201)
+        lg = X[((size_t)s * n_nodes + v) * ns + i];
+        x = lg;
+    }
+    const float m = wave_max(x);
+    const float se = wave_sum(lane < max_deg ? expf(x - m) : 0.f);
+    const float lse = m + logf(se);
+    if (lane < max_deg) {
+        logits[(size_t)n * max_deg + lane] = lg;
+        logp[(size_t)n * max_deg + lane] = lg - lse;
+    }
+}
+
+__global__ __launch_bounds__(64) void node_readout_bwd_kernel(int ns, int n_nodes, const float* __restrict__ X,
+                                                              const int32_t* __restrict__ nbr, int max_deg,
+                                                              const int32_t* __restrict__ last_nodes,
+                                                              const float* __restrict__ d_logp,
+                                                              const float* __restrict__ logp, int act,
+                                                              float* __restrict__ dz) {
+    __shared__ float dl[RO_MAXD];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    const float g = lane < max_deg ? d_logp[(size_t)n * max_deg + lane] : 0.f;
+    const float gs = wave_sum(g);
+    if (lane < max_deg) dl[lane] = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
+    __syncthreads();
+    if (lane == 0) {                                   // serial: several padded entries may hit the same node
+        for (int d = 0; d < max_deg; ++d) {
+            int v = nbr[(size_t)vlast * max_deg + d];
+            if (v < 0) v += n_nodes;
+            const size_t o = ((size_t)s * n_nodes + v) * ns + i;
+            dz[o] += dl[d] * act_grad_from_output(act, X[o]);
+        }
+    }
+}
+
+__global__ void scatter_flows_kernel(int ns, int n_edges, int64_t n_entries, const int32_t* __restrict__ sample_of,
+                                     const int32_t* __restrict__ edge_idx, const float* __restrict__ val,
+                                     float* __restrict__ x) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_entries) return;
+    const int n = sample_of[t];
+    const int s = n / ns, i = n - s * ns;
+    x[((size_t)s * n_edges + edge_idx[t]) * ns + i] = val[t];
+}
+
+__global__ void adam_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float c1, float c2,
+                            float wd2, float g_scale) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float wi = w[t];
+    const float gi = fmaf(g[t], g_scale, wd2 * wi);
+    const float mi = (1.f - b1) * gi + b1 * m[t];
+    const float vi = (1.f - b2) * gi * gi + b2 * v[t];
+    m[t] = mi;
+    v[t] = vi;
+    w[t] = wi - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+}
+
+}  // namespace scn
+
+using namespace scn;
+
+extern "C" {
+
+int scn_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c, const float* H,
+                        const float* w_last, const int32_t* nbr, int32_t n_nodes, int32_t max_deg,
+                        const int32_t* last_nodes, const int32_t* inc_ptr, const int32_t* inc_edge,
+                        const float* inc_sign, float* bh, float* logits, float* logp, void* stream) {
+    if (!H || !w_last || !nbr || !last_nodes || !inc_ptr || !inc_edge || !inc_sign || !bh || !logits || !logp)
+        return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
+    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, H,
+                       w_last, nbr, max_deg, last_nodes, inc_ptr, inc_edge, inc_sign, bh, logits, logp);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c, const float* H,
+                         const float* w_last, const int32_t* nbr, int32_t n_nodes, int32_t max_deg,
+                         const int32_t* last_nodes, const int32_t* inc_ptr, const int32_t* inc_edge,
+                         const float* inc_sign, const int32_t* edge_nodes, const float* bh, const float* d_logp,
+                         const float* logp, int32_t act, float* d_logits, float* dz, float* d_w_last,
+                         void* stream) {
+    if (!H || !w_last || !nbr || !last_nodes || !inc_ptr || !inc_edge || !inc_sign || !edge_nodes || !bh ||
+        !d_logp || !logp || !d_logits || !dz || !d_w_last)
+        return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
+    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = n_slabs * ns;
+    SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
+    float* dl = d_logits;
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
+                       last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(readout_dw_kernel, dim3((c + 63) / 64), dim3(64), 0, st, N * max_deg, c, dl, bh, d_w_last);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_node_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_nodes, const float* nodes_out,
+                             const int32_t* nbr, int32_t max_deg, const int32_t* last_nodes, float* logits,
+                             float* logp, void* stream) {
+    if (!nodes_out || !nbr || !last_nodes || !logits || !logp) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
+    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(node_readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_nodes,
+                       nodes_out, nbr, max_deg, last_nodes, logits, logp);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes, const float* nodes_out,
+                              const int32_t* nbr, int32_t max_deg, const int32_t* last_nodes, const float* d_logp,
+                              const float* logp, int32_t act, float* dz, void* stream) {
+    if (!nodes_out || !nbr || !last_nodes || !d_logp || !logp || !dz) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
+    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = n_slabs * ns;
+    SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_nodes, st));
+    hipLaunchKernelGGL(node_readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_nodes, nodes_out, nbr, max_deg,
+                       last_nodes, d_logp, logp, act, dz);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_entries, const int32_t* sample_of,
+                      const int32_t* edge_idx, const float* val, float* x, void* stream) {
+    if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || n_entries < 0) return SCN_ERR_BAD_SHAPE;
+    if (!x || (n_entries > 0 && (!sample_of || !edge_idx || !val))) return SCN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    SCN_HIP_TRY(hipMemsetAsync(x, 0, sizeof(float) * (size_t)n_slabs * n_edges * ns, st));
+    if (n_entries) {
+        hipLaunchKernelGGL(scatter_flows_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, st, ns,
+                           n_edges, n_entries, sample_of, edge_idx, val, x);
+        SCN_LAUNCH_CHECK();
+    }
+    return SCN_OK;
+}
+
+int scn_adam_step(int64_t n, float* w, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                  int32_t step_i, float weight_decay, float g_scale, void* stream) {
+    if (n <= 0 || step_i < 0) return SCN_ERR_BAD_SHAPE;
+    if (!w || !g || !m || !v) return SCN_ERR_BAD_ARG;
+    const float c1 = 1.f - powf(b1, (float)(step_i + 1));
+    const float c2 = 1.f - powf(b2, (float)(step_i + 1));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, w, g, m,
+                       v, lr, b1, b2, eps, c1, c2, 2.f * weight_decay, g_scale);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+}  // extern "C"

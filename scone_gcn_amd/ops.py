@@ -1,0 +1,432 @@
+"""Device-side operators: thin PyTorch-ROCm plumbing over the C-ABI (device memory, streams) -- no math here.
+
+ConvOp wraps a scn_conv_t; SconePlan / BunchPlan hold everything one model needs on the device and
+expose forward / backward over "flow slabs" ([n_slabs, rows, ns, C] fp32, see include/scone_hip.h).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, GroupDesc, check, i32_array, ptr_array
+from .complex import Shift, union_pattern
+from .synthetic_data_gen import SparseFlows
+
+NS = 4   # trajectories per slab
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "expected a contiguous CUDA tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class ConvOp:
+    """One shift-convolution operator (scn_conv_t).  groups: list of dicts
+    {"mats": [scipy csr in DEVICE order] (0..2, same shape), "identity": bool, "n_cols": int}."""
+
+    def __init__(self, n_rows, groups):
+        lib = _lib.load()
+        self.n_rows = int(n_rows)
+        self.group_cols = []
+        self.slot_group = []
+        descs = (GroupDesc * len(groups))()
+        keep = []
+        for gi, g in enumerate(groups):
+            mats = g["mats"]
+            n_cols = int(g["n_cols"])
+            if mats:
+                rowptr, cols, vals = union_pattern(mats)
+            else:
+                rowptr, cols, vals = np.zeros(n_rows + 1, np.int32), np.zeros(0, np.int32), []
+            rowptr = np.ascontiguousarray(rowptr, np.int32)
+            cols = np.ascontiguousarray(cols, np.int32)
+            vals = [np.ascontiguousarray(v, np.float32) for v in vals]
+            keep += [rowptr, cols] + vals
+            d = descs[gi]
+            d.n_cols, d.identity, d.n_vals, d.nnz = n_cols, int(bool(g.get("identity"))), len(vals), len(cols)
+            d.rowptr = rowptr.ctypes.data
+            d.col = cols.ctypes.data if len(cols) else None
+            d.val0 = vals[0].ctypes.data if len(vals) > 0 and len(cols) else None
+            d.val1 = vals[1].ctypes.data if len(vals) > 1 and len(cols) else None
+            self.group_cols.append(n_cols)
+            self.slot_group += [gi] * (d.identity + d.n_vals)
+        h = ctypes.c_void_p()
+        check(lib.scn_conv_create(self.n_rows, len(groups), descs, ctypes.byref(h)), "scn_conv_create")
+        self.handle = h
+        self.n_groups = len(groups)
+        self.n_slots = len(self.slot_group)
+        self.nnz = [int(descs[g].nnz) for g in range(len(groups))]
+        self.n_vals = [int(descs[g].n_vals) for g in range(len(groups))]
+        del keep
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().scn_conv_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def plan_info(self):
+        nb, ms = ctypes.c_int32(0), ctypes.c_float(0)
+        check(_lib.load().scn_conv_plan_info(self.handle, ctypes.byref(nb), ctypes.byref(ms)), "scn_conv_plan_info")
+        return nb.value, ms.value
+
+    def forward(self, srcs, Ws, c_out, act, out=None):
+        lib = _lib.load()
+        S, ns = srcs[0].shape[0], srcs[0].shape[2]
+        assert len(srcs) == self.n_groups and len(Ws) == self.n_slots
+        c_in = []
+        for g, x in enumerate(srcs):
+            assert x.shape[0] == S and x.shape[1] == self.group_cols[g] and x.shape[2] == ns, "source slab shape"
+            c_in.append(x.shape[3])
+        for s, w in enumerate(Ws):
+            assert tuple(w.shape) == (c_in[self.slot_group[s]], c_out), "weight shape"
+        if out is None:
+            out = torch.empty((S, self.n_rows, ns, c_out), device=srcs[0].device, dtype=torch.float32)
+        check(lib.scn_conv_forward(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
+                                   ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out), _stream()),
+              "scn_conv_forward")
+        return out
+
+    def backward(self, dzs, Ws, aux, act, need_dx, dWs):
+        """dWs: list of tensors ACCUMULATED into.  Returns dx or None."""
+        lib = _lib.load()
+        S, ns, c_aux = aux.shape[0], aux.shape[2], aux.shape[3]
+        assert aux.shape[1] == self.n_rows and len(dzs) == self.n_groups
+        c_dz = []
+        for g, x in enumerate(dzs):
+            assert x.shape[0] == S and x.shape[1] == self.group_cols[g] and x.shape[2] == ns, "dz slab shape"
+            c_dz.append(x.shape[3])
+        for s, (w, dw) in enumerate(zip(Ws, dWs)):
+            assert tuple(w.shape) == (c_aux, c_dz[self.slot_group[s]]) and tuple(dw.shape) == tuple(w.shape)
+        cdz = i32_array(c_dz)
+        nbytes = lib.scn_conv_backward_workspace(self.handle, S, ns, cdz, c_aux)
+        ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
+        dx = torch.empty_like(aux) if need_dx else None
+        check(lib.scn_conv_backward(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
+                                    ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
+                                    _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
+                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              "scn_conv_backward")
+        return dx
+
+    def spmm_dual(self, x, dual=True):
+        lib = _lib.load()
+        S, rows, k = x.shape
+        assert rows == self.group_cols[0]
+        ya = torch.empty((S, self.n_rows, k), device=x.device, dtype=torch.float32)
+        yb = torch.empty_like(ya) if dual else None
+        check(lib.scn_spmm_dual(self.handle, S, k, _dev(x), _dev(ya), _dev(yb) if dual else None, _stream()),
+              "scn_spmm_dual")
+        return ya, yb
+
+
+# ----------------------------------------------------------------------------------------------
+# slabs
+# ----------------------------------------------------------------------------------------------
+
+def pad_count(n, ns=NS):
+    return (n + ns - 1) // ns * ns
+
+
+def flows_to_slabs(flow, layout, device, ns=NS):
+    """(N, E, 1) dense array/tensor or SparseFlows (caller's edge order) -> [S, E, ns, 1] in device row order."""
+    lib = _lib.load()
+    perm = layout.perm[1]
+    if isinstance(flow, SparseFlows):
+        N, E = len(flow), flow.n_edges
+        S = pad_count(N, ns) // ns
+        x = torch.empty((S, E, ns, 1), device=device, dtype=torch.float32)
+        sample = np.repeat(np.arange(N, dtype=np.int32), np.diff(flow.ptr))
+        sample_d = torch.from_numpy(sample).to(device)
+        edge_d = torch.from_numpy(perm[flow.idx].astype(np.int32)).to(device)
+        val_d = torch.from_numpy(np.ascontiguousarray(flow.val, np.float32)).to(device)
+        check(lib.scn_scatter_flows(S, ns, E, len(sample), _dev(sample_d, torch.int32), _dev(edge_d, torch.int32),
+                                    _dev(val_d), _dev(x), _stream()), "scn_scatter_flows")
+        return x, N
+    t = torch.as_tensor(flow)
+    N, E = t.shape[0], t.shape[1]
+    assert t.numel() == N * E, "flows must have one input channel (STM:261)"
+    t = t.reshape(N, E).to(device=device, dtype=torch.float32)
+    Np = pad_count(N, ns)
+    if Np != N:
+        t = torch.cat([t, t.new_zeros((Np - N, E))])
+    order = torch.from_numpy(layout.order[1]).to(device)
+    x = t.index_select(1, order).reshape(Np // ns, ns, E).permute(0, 2, 1).contiguous().unsqueeze(-1)
+    return x, N
+
+
+def slabs_to_batch(x, layout, level, n):
+    """[S, rows, ns, C] (device order) -> (n, rows, C) in the caller's order (debug / tests)."""
+    S, R, ns, C = x.shape
+    perm = torch.from_numpy(layout.perm[level]).to(x.device)
+    return x.permute(0, 2, 1, 3).reshape(S * ns, R, C)[:n].index_select(1, perm)
+
+
+def batch_to_slabs(t, layout, level, ns=NS):
+    """(N, rows, C) caller order -> [S, rows, ns, C] device order."""
+    N, R, C = t.shape
+    Np = pad_count(N, ns)
+    if Np != N:
+        t = torch.cat([t, t.new_zeros((Np - N, R, C))])
+    order = torch.from_numpy(layout.order[level]).to(t.device)
+    return t.index_select(1, order).reshape(Np // ns, ns, R, C).permute(0, 2, 1, 3).contiguous()
+
+
+def _last_nodes_dev(last_nodes, n_pad, device):
+    ln = np.zeros(n_pad, np.int32)
+    a = last_nodes.detach().cpu().numpy() if torch.is_tensor(last_nodes) else np.asarray(last_nodes)
+    ln[:len(a)] = a
+    return torch.from_numpy(ln).to(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# scone / ebli
+# ----------------------------------------------------------------------------------------------
+
+class SconePlan:
+    """Device state of a scone/ebli model: the fused conv operator (identity + S_lower + S_upper on their shared
+    pattern), its transpose when the shifts are not symmetric, and the readout tables."""
+
+    def __init__(self, S_lower, S_upper, bconds, act, device):
+        assert isinstance(S_lower, Shift) and isinstance(S_upper, Shift), "shifts must come from SimplicialComplex"
+        self.layout = S_lower.layout
+        self.act = act
+        self.device = device
+        E = S_lower.shape[0]
+        self.n_edges = E
+        lo, up = S_lower.device_csr(), S_upper.device_csr()
+        self.conv = ConvOp(E, [{"mats": [lo, up], "identity": True, "n_cols": E}])
+        if S_lower.is_symmetric() and S_upper.is_symmetric():
+            self.conv_T = self.conv
+        else:
+            self.conv_T = ConvOp(E, [{"mats": [lo.T.tocsr(), up.T.tocsr()], "identity": True, "n_cols": E}])
+        self.nnz_pattern = self.conv.nnz[0]
+        self.nnz_lower, self.nnz_upper = int(lo.nnz), int(up.nnz)
+        ptr, edge, sign, edge_nodes = bconds.incidence_tables()
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.inc_ptr, self.inc_edge, self.inc_sign, self.edge_nodes = to(ptr), to(edge), to(sign), to(edge_nodes)
+        self.nbr = to(bconds.nbrhoods.astype(np.int32))
+        self.n_nodes, self.max_deg = bconds.nbrhoods.shape
+
+    # -- raw forward/backward over slabs (no autograd): used by the autograd Function and by the trainer
+    def conv_stack(self, x, weights):
+        n_layers = (len(weights) - 1) / 3
+        assert n_layers % 1 == 0, "wrong number of weights"                    # TE:141-142
+        hs = [x]
+        for i in range(int(n_layers)):
+            w = weights[3 * i:3 * i + 3]
+            hs.append(self.conv.forward([hs[-1]], w, w[0].shape[1], self.act))
+        return hs
+
+    def readout(self, H, w_last, last_dev):
+        lib = _lib.load()
+        S, E, ns, C = H.shape
+        N = S * ns
+        assert tuple(w_last.shape) == (C, 1), "readout weight must be (C, 1) (STM:233, out_channels = 1)"
+        bh = torch.empty((N, self.max_deg, C), device=H.device, dtype=torch.float32)
+        logits = torch.empty((N, self.max_deg), device=H.device, dtype=torch.float32)
+        logp = torch.empty_like(logits)
+        check(lib.scn_readout_forward(S, ns, E, C, _dev(H), _dev(w_last), _dev(self.nbr, torch.int32), self.n_nodes,
+                                      self.max_deg, _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
+                                      _dev(self.inc_edge, torch.int32), _dev(self.inc_sign), _dev(bh), _dev(logits),
+                                      _dev(logp), _stream()), "scn_readout_forward")
+        return logp, bh, logits
+
+    def forward(self, x, last_dev, weights):
+        hs = self.conv_stack(x, weights)
+        logp, bh, _ = self.readout(hs[-1], weights[-1], last_dev)
+        return logp, (hs, bh)
+
+    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        """grads: list of tensors (same shapes as weights) accumulated into."""
+        lib = _lib.load()
+        hs, bh = saved
+        H = hs[-1]
+        S, E, ns, C = H.shape
+        dz = torch.empty_like(H)
+        d_logits = torch.empty_like(logp)
+        d_logp = d_logp.contiguous()
+        check(lib.scn_readout_backward(S, ns, E, C, _dev(H), _dev(weights[-1]), _dev(self.nbr, torch.int32),
+                                       self.n_nodes, self.max_deg, _dev(last_dev, torch.int32),
+                                       _dev(self.inc_ptr, torch.int32), _dev(self.inc_edge, torch.int32),
+                                       _dev(self.inc_sign), _dev(self.edge_nodes, torch.int32), _dev(bh),
+                                       _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz),
+                                       _dev(grads[-1]), _stream()), "scn_readout_backward")
+        L = len(hs) - 1
+        for i in reversed(range(L)):
+            dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+        return grads
+
+
+class _SconeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, last_dev, *weights):
+        logp, saved = plan.forward(x, last_dev, weights)
+        ctx.plan, ctx.saved, ctx.last_dev = plan, saved, last_dev
+        ctx.save_for_backward(logp, *weights)
+        return logp
+
+    @staticmethod
+    def backward(ctx, d_logp):
+        logp, *weights = ctx.saved_tensors
+        grads = [torch.zeros_like(w) for w in weights]
+        ctx.plan.backward(ctx.saved, logp, d_logp, ctx.last_dev, weights, grads)
+        ctx.saved = None
+        return (None, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# bunch
+# ----------------------------------------------------------------------------------------------
+
+BUNCH_SRC = [0, 1, 0, 1, 2, 1, 2]      # input level of weight slot k   (TE:184-192)
+BUNCH_DST = [0, 0, 1, 1, 1, 2, 2]      # output level of weight slot k
+
+
+class BunchPlan:
+    """Device state of the Bunch (SCCONV) model: one conv operator per output level (forward) and one per input
+    level built from the transposed shifts (backward)."""
+
+    def __init__(self, shifts, nbrhoods, device):
+        assert len(shifts) == 7 and all(isinstance(s, Shift) for s in shifts)
+        self.layout = shifts[0].layout
+        self.device = device
+        self.sizes = self.layout.sizes
+        dev = [s.device_csr() for s in shifts]
+        self.fwd, self.fwd_slots = [], []
+        self.bwd, self.bwd_slots = [], []
+        for lvl in range(3):
+            ks = [k for k in range(7) if BUNCH_DST[k] == lvl]
+            self.fwd_slots.append(ks)
+            self.fwd.append(ConvOp(self.sizes[lvl], [{"mats": [dev[k]], "identity": False,
+                                                      "n_cols": self.sizes[BUNCH_SRC[k]]} for k in ks]))
+            ks = [k for k in range(7) if BUNCH_SRC[k] == lvl]
+            self.bwd_slots.append(ks)
+            self.bwd.append(ConvOp(self.sizes[lvl], [{"mats": [dev[k].T.tocsr()], "identity": False,
+                                                      "n_cols": self.sizes[BUNCH_DST[k]]} for k in ks]))
+        nb = np.asarray(nbrhoods)
+        pn = self.layout.perm[0]
+        nbd = np.where(nb >= 0, pn[np.maximum(nb, 0)], -1)
+        if not self.layout.is_identity(0):
+            raise NotImplementedError("node reordering is not used by the bunch readout (-1 wraps to node V-1)")
+        self.nbr = torch.from_numpy(np.ascontiguousarray(nbd, np.int32)).to(device)
+        self.max_deg = nb.shape[1]
+
+    def conv_stack(self, x, weights):
+        n_layers = len(weights) / 7
+        assert n_layers % 1 == 0, "wrong number of weights"                    # TE:177-178
+        S, E, ns, _ = x.shape
+        cur = [torch.zeros((S, self.sizes[0], ns, 1), device=x.device), x,
+               torch.zeros((S, self.sizes[2], ns, 1), device=x.device)]         # TE:179
+        states = [cur]
+        for i in range(int(n_layers)):
+            nxt = []
+            for lvl in range(3):
+                ks = self.fwd_slots[lvl]
+                Ws = [weights[7 * i + k] for k in ks]
+                nxt.append(self.fwd[lvl].forward([cur[BUNCH_SRC[k]] for k in ks], Ws, Ws[0].shape[1], "relu"))
+            cur = nxt
+            states.append(cur)
+        return states
+
+    def forward(self, x, last_dev, weights):
+        lib = _lib.load()
+        states = self.conv_stack(x, weights)
+        nodes_out = states[-1][0]
+        S, V, ns, C = nodes_out.shape
+        assert C == 1, "bunch readout needs one output channel (TE:198-201)"
+        logits = torch.empty((S * ns, self.max_deg), device=x.device, dtype=torch.float32)
+        logp = torch.empty_like(logits)
+        check(lib.scn_node_readout_forward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
+                                           _dev(last_dev, torch.int32), _dev(logits), _dev(logp), _stream()),
+              "scn_node_readout_forward")
+        return logp, states
+
+    def backward(self, states, logp, d_logp, last_dev, weights, grads):
+        lib = _lib.load()
+        nodes_out = states[-1][0]
+        S, V, ns, _ = nodes_out.shape
+        dz = [torch.empty_like(nodes_out), torch.zeros_like(states[-1][1]), torch.zeros_like(states[-1][2])]
+        check(lib.scn_node_readout_backward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
+                                            _dev(last_dev, torch.int32), _dev(d_logp.contiguous()), _dev(logp),
+                                            ACT["relu"], _dev(dz[0]), _stream()), "scn_node_readout_backward")
+        L = len(states) - 1
+        for i in reversed(range(L)):
+            x = states[i]
+            new_dz = [None, None, None]
+            for lvl in range(3):
+                ks = self.bwd_slots[lvl]
+                Ws = [weights[7 * i + k] for k in ks]
+                dWs = [grads[7 * i + k] for k in ks]
+                new_dz[lvl] = self.bwd[lvl].backward([dz[BUNCH_DST[k]] for k in ks], Ws, x[lvl], "relu", i > 0, dWs)
+            dz = new_dz
+        return grads
+
+
+class _BunchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, last_dev, *weights):
+        logp, states = plan.forward(x, last_dev, weights)
+        ctx.plan, ctx.states, ctx.last_dev = plan, states, last_dev
+        ctx.save_for_backward(logp, *weights)
+        return logp
+
+    @staticmethod
+    def backward(ctx, d_logp):
+        logp, *weights = ctx.saved_tensors
+        grads = [torch.zeros_like(w) for w in weights]
+        ctx.plan.backward(ctx.states, logp, d_logp, ctx.last_dev, weights, grads)
+        ctx.states = None
+        return (None, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# plan cache + micro-batching
+# ----------------------------------------------------------------------------------------------
+
+def get_scone_plan(S_lower, S_upper, bconds, act, device):
+    key = ("scone", id(S_upper), id(bconds), act, str(device))
+    if key not in S_lower._cache:
+        S_lower._cache[key] = SconePlan(S_lower, S_upper, bconds, act, device)
+    return S_lower._cache[key]
+
+
+def get_bunch_plan(shifts, nbrhoods, device):
+    key = ("bunch",) + tuple(id(s) for s in shifts[1:]) + (str(device),)
+    if key not in shifts[0]._cache:
+        shifts[0]._cache[key] = BunchPlan(shifts, nbrhoods, device)
+    return shifts[0]._cache[key]
+
+
+def micro_batch_size(n_rows_total, widths, n, ns=NS, budget_bytes=None, device=None):
+    """Trajectories per micro-batch so that saved activations + two gradient buffers fit the budget."""
+    if budget_bytes is None:
+        free, total = torch.cuda.mem_get_info(device)
+        budget_bytes = 0.35 * total
+    per_sample = 4.0 * n_rows_total * (sum(widths) + 2 * max(widths))
+    mb = int(budget_bytes // max(per_sample, 1.0))
+    mb = max(ns, min(mb, 16384) // ns * ns)
+    return min(mb, pad_count(n, ns))
+
+
+def as_device_weights(weights, device):
+    out = []
+    for w in weights:
+        t = w if torch.is_tensor(w) else torch.as_tensor(np.asarray(w))
+        if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device=device, dtype=torch.float32).contiguous()
+        out.append(t)
+    return out
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("scone_gcn_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())

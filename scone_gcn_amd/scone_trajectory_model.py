@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference trainer class (trajectory_analysis/scone_trajectory_model.py = STM).
+
+Scone_GCN keeps the reference's constructor, attributes and methods
+    Scone_GCN(epochs, step_size, batch_size, weight_decay, verbose=True)           STM:18
+    .setup(model, hidden_layers, shifts, inputs, y, in_axes, train_mask, model_type='scone')   STM:245
+    .loss(weights, inputs, y, mask)   .accuracy(shifts, inputs, y, mask, n_nbrs)    STM:42, 59
+    .train(inputs, y, train_mask, test_mask, n_nbrs) -> (train_loss, train_acc, test_loss, test_acc)   STM:264
+    .test(inputs, y, mask, n_nbrs) -> (loss, acc)    .two_target_accuracy(...)      STM:359, 73
+    .generate_weights(in_channels, hidden_layers, out_channels)    .weights         STM:215
+but runs the hot path on the GPU: forward/backward through libscone_hip.so on only the trajectories a mask
+selects (the reference runs all N and masks afterwards, STM:46 -- same value), the whole weight list in one flat
+fp32 buffer so that the gradient all-reduce and the fused Adam/ridge kernel see a single array, and the batch
+sharded over ranks when torch.distributed is initialised (scone_gcn_amd/distributed.py).
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import distributed as dp
+from .synthetic_data_gen import SparseFlows
+from .trajectory_experiments import MODEL_ACT, MODEL_FUNCS
+
+# module-level legacy RNG seeded like the reference's `onp.random.seed(1030)` at import (STM:15): weights
+# (STM:237), batch-mask shuffles (STM:320) and random targets (STM:79, 91) are drawn from it in call order.
+_RNG = np.random.RandomState(1030)
+
+
+def reseed(seed=1030):
+    global _RNG
+    _RNG = np.random.RandomState(seed)
+
+
+def _select(inputs, idx):
+    """Rows idx of the per-trajectory inputs [readout operand, last_nodes, X]."""
+    X = inputs[-1]
+    if isinstance(X, SparseFlows):
+        Xs = X.select(idx)
+    elif torch.is_tensor(X):
+        Xs = X[torch.as_tensor(idx, device=X.device)]
+    else:
+        Xs = np.asarray(X)[idx]
+    return [inputs[0], np.asarray(inputs[1])[idx], Xs]
+
+
+def _n_samples(X):
+    return len(X) if isinstance(X, SparseFlows) else X.shape[0]
+
+
+class Scone_GCN():
+    def __init__(self, epochs, step_size, batch_size, weight_decay, verbose=True, process_group=None):
+        self.random_targets = None
+        self.trained = False
+        self.model = None
+        self.model_single = None
+        self.shifts = None
+        self.weights = None
+        self.epochs = int(epochs)                      # STM:35-38
+        self.step_size = step_size
+        self.batch_size = int(batch_size)
+        self.weight_decay = weight_decay
+        self.verbose = verbose
+        self.process_group = process_group
+        self.model_type = 'scone'
+        self._flat_w = self._flat_g = self._m = self._v = None
+        self._step = 0
+
+    # ------------------------------------------------------------------ weights
+    def generate_weights(self, in_channels, hidden_layers, out_channels):
+        """Same shapes, order and 0.01 * randn values as STM:215-242 (fp32 on the device)."""
+        weight_shapes = []
+        if len(hidden_layers) > 0:
+            weight_shapes += [(in_channels, hidden_layers[0][1])] * hidden_layers[0][0]
+            for i in range(len(hidden_layers) - 1):
+                for _ in range(hidden_layers[i + 1][0]):
+                    weight_shapes += [(hidden_layers[i][1], hidden_layers[i + 1][1])]
+            if self.model_type == 'bunch':
+                weight_shapes += [(hidden_layers[-1][1], out_channels)] * hidden_layers[-1][0]
+            else:
+                weight_shapes += [(hidden_layers[-1][1], out_channels)]
+            host = [0.01 * _RNG.randn(*s) for s in weight_shapes]
+        else:
+            raise ValueError("at least one hidden layer is required")
+        self._install(host)
+        if self.verbose:
+            print('# of parameters: {}'.format(int(np.sum([np.prod(s) for s in weight_shapes]))))
+
+    def _install(self, host_weights):
+        device = ops.default_device()
+        sizes = [int(np.prod(w.shape)) for w in host_weights]
+        flat = np.concatenate([np.asarray(w, np.float64).ravel() for w in host_weights]).astype(np.float32)
+        self._flat_w = torch.from_numpy(flat).to(device)
+        self._flat_g = torch.zeros_like(self._flat_w)
+        self._m = torch.zeros_like(self._flat_w)
+        self._v = torch.zeros_like(self._flat_w)
+        self._offsets = np.concatenate([[0], np.cumsum(sizes)])
+        self._shapes = [tuple(w.shape) for w in host_weights]
+        self.weights = self._views(self._flat_w)
+        self._grads = self._views(self._flat_g)
+
+    def _views(self, flat):
+        return [flat[self._offsets[k]:self._offsets[k + 1]].view(self._shapes[k]) for k in range(len(self._shapes))]
+
+    def save_weights(self, path):
+        """Pickle-free replacement of onp.save('models/<name>', weights) (TE:482-486)."""
+        np.savez(path, **{"w%d" % k: w.detach().cpu().numpy() for k, w in enumerate(self.weights)})
+
+    def load_weights(self, path):
+        d = np.load(path)
+        self._install([d["w%d" % k] for k in range(len(d.files))])
+
+    # ------------------------------------------------------------------ setup
+    def setup(self, model, hidden_layers, shifts, inputs, y, in_axes, train_mask, model_type='scone'):
+        """Set up model for training / calling (STM:245-262).  `in_axes` is accepted for signature parity; the
+        model functions are batched natively."""
+        self.model_type = model_type
+        self.shifts = shifts
+        self.model = model
+        self.model_single = model
+        X = inputs[-1]
+        in_channels = 1 if isinstance(X, SparseFlows) else int(X.shape[-1])
+        out_channels = int(np.asarray(y).shape[-1])
+        self.generate_weights(in_channels, hidden_layers, out_channels)
+
+    def _plan(self, inputs):
+        if self.model is MODEL_FUNCS.get(self.model_type):
+            dev = ops.default_device()
+            if self.model_type == 'bunch':
+                return ops.get_bunch_plan(list(self.shifts), inputs[0], dev)
+            return ops.get_scone_plan(self.shifts[0], self.shifts[1], inputs[0], MODEL_ACT[self.model_type], dev)
+        return None
+
+    # ------------------------------------------------------------------ loss / metrics
+    def _ridge(self, weights):
+        return self.weight_decay * sum(float((w.double() ** 2).sum()) for w in weights)   # STM:54-56
+
+    def _predict(self, weights, inputs, idx=None):
+        """log-probabilities (n, D, 1) for trajectories idx (all when None), no autograd."""
+        sub = inputs if idx is None else _select(inputs, idx)
+        with torch.no_grad():
+            return self.model(weights, *self.shifts, *sub)
+
+    def loss(self, weights, inputs, y, mask):
+        """Cross-entropy per masked flow + ridge (STM:42-56).  Returns a Python float."""
+        idx = np.nonzero(np.asarray(mask) == 1)[0]
+        preds = self._predict(weights, inputs, idx)
+        yt = torch.as_tensor(np.asarray(y)[idx], device=preds.device, dtype=torch.float32)
+        return float(-(preds.double() * yt.double()).sum() / len(idx)) + self._ridge(weights)
+
+    def accuracy(self, shifts, inputs, y, mask, n_nbrs):
+        """Ratio of correct predictions among the true neighbours (STM:59-71)."""
+        idx = np.nonzero(np.asarray(mask) == 1)[0]
+        target_choice = np.argmax(np.asarray(y)[idx], axis=1)
+        preds = self._predict(self.weights, inputs, idx).cpu().numpy().astype(np.float64)
+        nn = np.asarray(n_nbrs)[idx]
+        for i in range(len(preds)):
+            preds[i, nn[i]:] = -100
+        pred_choice = np.argmax(preds, axis=1)
+        return float(np.mean(pred_choice == target_choice))
+
+    def two_target_accuracy(self, shifts, inputs, y, mask, n_nbrs):
+        """STM:73-108, including its quirk of re-drawing against the PREDICTED choice."""
+        N = _n_samples(inputs[-1])
+        n_nbrs = np.asarray(n_nbrs)
+        if type(self.random_targets) != np.ndarray:
+            self.random_targets = _RNG.randint(0, high=n_nbrs, size=N)
+        preds = self._predict(self.weights, inputs).cpu().numpy().astype(np.float64)
+        for i in range(len(preds)):
+            preds[i, n_nbrs[i]:] = -100
+        m = np.asarray(mask) == 1
+        pred_choice = np.argmax(preds[m], axis=1)
+        for i in range(min(preds.shape[0], len(pred_choice))):
+            while n_nbrs[i] > 1 and self.random_targets[i] == pred_choice[i]:
+                self.random_targets[i] = _RNG.randint(0, high=n_nbrs[i])
+        rows = np.arange(N)
+        random_probs = preds[rows, self.random_targets, 0]
+        true_choice = np.argmax(np.asarray(y), axis=1).reshape((N,))
+        true_probs = preds[rows, true_choice, 0]
+        t, r = true_probs[m], random_probs[m]
+        return float((np.sum(t > r) + 0.5 * np.sum(t == r)) / np.sum(m))
+
+    # ------------------------------------------------------------------ gradient step (STM:306-310)
+    def _accumulate_grad(self, plan, inputs, y, idx, total):
+        """flat_g += d/dW of  -sum_{n in idx} <logp_n, y_n> / total, micro-batched.  Returns that partial loss as a
+        0-dim device tensor (no host synchronisation inside the step)."""
+        device = self._flat_w.device
+        k = 7 if self.model_type == 'bunch' else 3
+        widths = [1] + [self._shapes[k * i][1] for i in range(len(self._shapes) // k)]
+        rows = sum(plan.sizes) if self.model_type == 'bunch' else plan.n_edges
+        mb = ops.micro_batch_size(rows, widths, len(idx), device=device)
+        part = torch.zeros((), device=device, dtype=torch.float64)
+        for c0 in range(0, len(idx), mb):
+            sel = idx[c0:c0 + mb]
+            sub = _select(inputs, sel)
+            x, n = ops.flows_to_slabs(sub[2], plan.layout, device)
+            last_dev = ops._last_nodes_dev(sub[1], x.shape[0] * ops.NS, device)
+            logp, saved = plan.forward(x, last_dev, self.weights)
+            yt = torch.zeros((x.shape[0] * ops.NS, logp.shape[1]), device=device, dtype=torch.float32)
+            yt[:n] = torch.as_tensor(np.asarray(y)[sel], dtype=torch.float32).reshape(n, -1).to(device)
+            d_logp = yt * (-1.0 / total)
+            part += (logp.double() * d_logp.double()).sum()
+            plan.backward(saved, logp, d_logp, last_dev, self.weights, self._grads)
+            del saved
+        return part
+
+    def grad_step(self, inputs, y, batch_mask, apply=True):
+        """One optimiser step on the masked batch: gradient of self.loss (STM:307) + Adam update (STM:310, 326).
+        Returns this rank's share of the data term of the loss as a 0-dim device tensor (sum over ranks = the
+        batch cross-entropy; the ridge term is not included)."""
+        idx = np.nonzero(np.asarray(batch_mask) == 1)[0]
+        plan = self._plan(inputs)
+        if plan is None:
+            return self._grad_step_autograd(inputs, y, idx, apply)
+        acc = {}
+
+        def grad_fn(local, total):
+            acc["loss"] = self._accumulate_grad(plan, inputs, y, local, total)
+        dp.data_parallel_grad(idx, grad_fn, self._flat_g, self.process_group)
+        if apply:
+            self._adam()
+        return acc.get("loss", torch.zeros((), device=self._flat_w.device, dtype=torch.float64))
+
+    def _grad_step_autograd(self, inputs, y, idx, apply):
+        """Fallback for a user-supplied differentiable model callable (still GPU-only)."""
+        ws = [w.detach().requires_grad_(True) for w in self.weights]
+        sub = _select(inputs, idx)
+        preds = self.model(ws, *self.shifts, *sub)
+        yt = torch.as_tensor(np.asarray(y)[idx], device=preds.device, dtype=torch.float32)
+        data = -(preds * yt).sum() / len(idx)
+        gs = torch.autograd.grad(data, ws)
+        self._flat_g.zero_()
+        for g, v in zip(gs, self._grads):
+            v.add_(g)
+        dp.all_reduce_sum_(self._flat_g, self.process_group)
+        if apply:
+            self._adam()
+        return data.detach().double()
+
+    def _adam(self):
+        """Fused ridge + Adam on the flat buffer: g + 2*wd*w, b1=.9, b2=.999, eps=1e-8 outside the sqrt, (i+1) bias
+        correction -- jax.experimental.optimizers.adam as driven by STM:300-326."""
+        lib = _lib.load()
+        _lib.check(lib.scn_adam_step(self._flat_w.numel(), ops._dev(self._flat_w), ops._dev(self._flat_g),
+                                     ops._dev(self._m), ops._dev(self._v), float(self.step_size), 0.9, 0.999, 1e-8,
+                                     int(self._step), float(self.weight_decay), 1.0, ops._stream()), "scn_adam_step")
+        self._step += 1
+
+    # ------------------------------------------------------------------ train / test
+    def train(self, inputs, y, train_mask, test_mask, n_nbrs):
+        """Trains a batched model to predict y (STM:264-357)."""
+        N = _n_samples(inputs[-1])
+        train_mask, test_mask = np.asarray(train_mask), np.asarray(test_mask)
+        n_train_samples = int(np.sum(train_mask))
+        n_batches = n_train_samples // self.batch_size
+        self._m.zero_(); self._v.zero_(); self._step = 0          # adam state re-initialised (STM:312)
+        unshuffled_batch_mask = np.array([1] * self.batch_size + [0] * (N - self.batch_size))
+        train_loss = train_acc = test_loss = test_acc = None
+        for i in range(self.epochs * n_batches):                  # STM:318
+            batch_mask = np.array(unshuffled_batch_mask)
+            _RNG.shuffle(batch_mask)
+            batch_mask = np.logical_and(batch_mask, train_mask)
+            if batch_mask.sum() == 0:
+                continue
+            self.grad_step(inputs, y, batch_mask)
+            if i % n_batches == n_batches - 1:                    # STM:328-337
+                train_loss = self.loss(self.weights, inputs, y, train_mask)
+                train_acc = self.accuracy(self.shifts, inputs, y, train_mask, n_nbrs)
+                test_loss = self.loss(self.weights, inputs, y, test_mask)
+                test_acc = self.accuracy(self.shifts, inputs, y, test_mask, n_nbrs)
+                if self.verbose and dp.world(self.process_group)[0] == 0:
+                    print('Epoch {} -- train loss: {:.6f} -- train acc {:.3f} -- test loss {:.6f} -- test acc {:.3f}'
+                          .format(i // n_batches, train_loss, train_acc, test_loss, test_acc))
+        if self.verbose and dp.world(self.process_group)[0] == 0:
+            print("Epochs: {}, learning rate: {}, batch size: {}, model: {}".format(
+                self.epochs, self.step_size, self.batch_size, getattr(self.model, '__name__', str(self.model))))
+        self.trained = True
+        return train_loss, train_acc, test_loss, test_acc
+
+    def test(self, test_inputs, y, test_mask, n_nbrs):
+        """Return the loss and accuracy for the given inputs (STM:359-368)."""
+        loss = self.loss(self.weights, test_inputs, y, test_mask)
+        acc = self.accuracy(self.shifts, test_inputs, y, test_mask, n_nbrs)
+        if self.verbose:
+            print("Test loss: {:.6f}, Test acc: {:.3f}".format(loss, acc))
+        return loss, acc

@@ -1,0 +1,268 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Tolerance: BASELINE.json's north_star asks for <= 1e-5 max deviation (fp32) on forward and backward outputs.
+Inputs are the committed golden fixtures of config 1 (tests/golden) plus seeded synthetic complexes.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import scone_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.fixture(scope="module")
+def sc1(cfg1):
+    _need_gpu()
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.synthetic_data_gen import Complex
+    cx = Complex(n_nodes=cfg1["n_nodes"], edges=cfg1["edges"].astype(np.int64), faces=cfg1["faces"].astype(np.int64),
+                 coords=cfg1["coords"])
+    return SimplicialComplex(cx)
+
+
+def _rand_weights(shapes, scale, seed):
+    rs = np.random.RandomState(seed)
+    return [scale * rs.randn(*s) for s in shapes]
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def _oracle_scone(cfg1, weights, sel, model, flips=None):
+    B1, B2 = cfg1["B1"], cfg1["B2"]
+    F = np.diag(flips) if flips is not None else None
+    shifts = so.scone_shifts(B1, B2, F) if model == "scone" else so.ebli_shifts(B1, B2, F)
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    Bc = so.make_Bconds(B1, nb, F)
+    X = cfg1["flows"][sel]
+    if flips is not None:
+        X = X * flips[None, :, None]
+    act = "tanh" if model == "scone" else "leaky_relu"
+    return shifts, Bc, X, act
+
+
+@pytest.mark.parametrize("model,hidden", [("scone", 16), ("scone", 32), ("ebli", 16), ("scone", 8)])
+def test_forward_and_gradients_match_oracle(cfg1, sc1, model, hidden):
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(0, 27)            # not a multiple of the slab width on purpose
+    shapes = so.weight_shapes(1, [(3, hidden)] * 3, 1)
+    w = _rand_weights(shapes, 0.25, 7)
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, model)
+    y, last = cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    mask = np.ones(len(sel), int)
+    mask[[3, 11]] = 0
+    ref_out = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, last, X, act)
+    ref_loss, ref_g = so.scone_loss_and_grad(w, shifts_o[0], shifts_o[1], Bc, last, X, y, mask, 0.0, act)
+
+    shifts, readout, _ = te.setup_from_complex(sc1, model)
+    fn = te.MODEL_FUNCS[model]
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = fn(wt, *shifts, readout, last, X)
+    assert out.shape == (len(sel), cfg1["D"], 1)
+    assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
+    m = torch.as_tensor(mask, device="cuda").bool()
+    yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
+    loss = -(out[m] * yt[m]).sum() / m.sum()
+    loss.backward()
+    assert abs(float(loss) - ref_loss) <= TOL
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
+def test_single_sample_call(cfg1, sc1):
+    from scone_gcn_amd import trajectory_experiments as te
+    shapes = so.weight_shapes(1, [(3, 16)] * 3, 1)
+    w = _rand_weights(shapes, 0.25, 3)
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, np.array([5]), "scone")
+    ref = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, cfg1["last_nodes"][[5]], X)[0]
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    out = te.scone_func(w, *shifts, readout, int(cfg1["last_nodes"][5]), cfg1["flows"][5])
+    assert out.shape == (cfg1["D"], 1)
+    assert _maxdiff(out.cpu().numpy(), ref) <= TOL
+
+
+def test_sparse_and_dense_flows_agree(cfg1, sc1):
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.synthetic_data_gen import SparseFlows
+    sel = np.arange(40, 72)
+    shapes = so.weight_shapes(1, [(3, 16)] * 3, 1)
+    w = _rand_weights(shapes, 0.25, 5)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    dense = te.scone_func(w, *shifts, readout, cfg1["last_nodes"][sel], cfg1["flows"][sel])
+    sparse = te.scone_func(w, *shifts, readout, cfg1["last_nodes"][sel], SparseFlows.fromdense(cfg1["flows"][sel]))
+    assert torch.equal(dense, sparse)
+
+
+def test_flip_invariance_tanh(cfg1, sc1):
+    """-flip_edges experiment (TE:43, 214-219, 242-244, 288-296): with an odd activation the log-probabilities do
+    not depend on edge orientation; with leaky_relu they do."""
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(100, 116)
+    shapes = so.weight_shapes(1, [(3, 16)] * 3, 1)
+    w = _rand_weights(shapes, 0.25, 9)
+    last = cfg1["last_nodes"][sel]
+    outs = {}
+    for model in ("scone", "ebli"):
+        for flip in (False, True):
+            shifts, readout, flips = te.setup_from_complex(sc1, model, flip_edges=flip)
+            X = te.apply_flips(cfg1["flows"][sel], flips)
+            outs[(model, flip)] = te.MODEL_FUNCS[model](w, *shifts, readout, last, X).cpu().numpy()
+    assert _maxdiff(outs[("scone", False)], outs[("scone", True)]) <= TOL
+    assert _maxdiff(outs[("ebli", False)], outs[("ebli", True)]) > 1e-4
+    # and the flipped scone path matches the oracle run on flipped operators
+    flips = sc1.flip_vector(1)
+    assert np.array_equal(np.diag(so.flip_matrix(cfg1["E"])), flips)
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, "scone", flips)
+    ref = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, last, X)
+    assert _maxdiff(outs[("scone", True)], ref) <= TOL
+
+
+@pytest.mark.parametrize("hidden", [8, 16])
+def test_bunch_matches_oracle(cfg1, sc1, hidden):
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(200, 214)
+    shapes = so.weight_shapes(1, [(7, hidden)] * 3, 1, "bunch")
+    w = _rand_weights(shapes, 0.4, 11)
+    S = so.bunch_shifts(cfg1["B1"], cfg1["B2"])
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    mask = np.ones(len(sel), int)
+    mask[2] = 0
+    ref_out = so.bunch_forward(w, S, nb, last, X)
+    ref_loss, ref_g = so.bunch_loss_and_grad(w, S, nb, last, X, y, mask, 0.0)
+
+    shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+    assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
+    m = torch.as_tensor(mask, device="cuda").bool()
+    yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
+    loss = -(out[m] * yt[m]).sum() / m.sum()
+    loss.backward()
+    assert abs(float(loss) - ref_loss) <= TOL
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
+def test_spmm_dual_matches_scipy(cfg1, sc1):
+    from scone_gcn_amd import ops
+    shifts = sc1.scone_shifts()
+    plan = ops.get_scone_plan(shifts[0], shifts[1], sc1.bconds(), "tanh", ops.default_device())
+    rs = np.random.RandomState(0)
+    for k in (1, 4, 64, 128, 100):
+        x = rs.randn(3, cfg1["E"], k).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        ya, yb = plan.conv.spmm_dual(xd)
+        lo, up = shifts[0].device_csr(), shifts[1].device_csr()
+        for s in range(3):
+            assert _maxdiff(ya[s].cpu().numpy(), lo @ x[s].astype(np.float64)) <= 2e-5
+            assert _maxdiff(yb[s].cpu().numpy(), up @ x[s].astype(np.float64)) <= 2e-5
+
+
+def test_trainer_step_matches_oracle_adam(cfg1, sc1):
+    """Scone_GCN.grad_step == oracle gradient + oracle Adam, for three consecutive steps on reference batches."""
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    stm.reseed(1030)
+    N = 200
+    sel = np.arange(N)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    inputs = [readout, cfg1["last_nodes"][sel], cfg1["flows"][sel]]
+    y, train_mask = cfg1["targets"][sel], cfg1["train_mask"][sel]
+    net = stm.Scone_GCN(1, 1e-3, 50, 5e-5, verbose=False)
+    net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, train_mask, model_type="scone")
+    w0 = so.generate_weights(1, [(3, 16)] * 3, 1)
+    for a, b in zip(net.weights, w0):
+        assert _maxdiff(a.cpu().numpy(), b) <= 1e-9          # same seed-1030 stream as STM:15, 237
+    shifts_o, Bc, _, act = _oracle_scone(cfg1, w0, sel, "scone")
+    adam = so.Adam([w.astype(np.float32).astype(np.float64) for w in w0], 1e-3)
+    rs_o = np.random.RandomState(1030)
+    [rs_o.randn(*s) for s in so.weight_shapes(1, [(3, 16)] * 3, 1)]   # the oracle's copy of the seed-1030 stream
+    for i in range(3):
+        bm_o = so.draw_batch_mask(rs_o, N, 50, train_mask)
+        bm = np.array([1] * 50 + [0] * (N - 50))
+        stm._RNG.shuffle(bm)
+        bm = np.logical_and(bm, train_mask)
+        assert np.array_equal(bm, bm_o)
+        ridge = 5e-5 * so.ridge(adam.x)
+        loss = float(net.grad_step(inputs, y, bm))
+        ref_loss, g = so.scone_loss_and_grad(adam.x, shifts_o[0], shifts_o[1], Bc, inputs[1], inputs[2], y, bm, 5e-5)
+        assert abs(loss + ridge - ref_loss) <= TOL
+        adam.update(i, g)
+        for a, b in zip(net.weights, adam.x):
+            assert _maxdiff(a.cpu().numpy(), b) <= 2e-6, "step %d" % i
+
+
+def test_loss_accuracy_and_reverse_inputs(cfg1, sc1):
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    stm.reseed(1030)
+    sel = np.arange(120)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    inputs = [readout, cfg1["last_nodes"][sel], cfg1["flows"][sel]]
+    y, mask = cfg1["targets"][sel], cfg1["test_mask"][sel]
+    net = stm.Scone_GCN(1, 1e-3, 50, 5e-5, verbose=False)
+    net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, mask, model_type="scone")
+    w = [a.cpu().numpy().astype(np.float64) for a in net.weights]
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, "scone")
+    out = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, inputs[1], X)
+    n_nbrs = sc1.n_nbrs(inputs[1])
+    assert abs(net.loss(net.weights, inputs, y, mask) - so.loss_from_preds(out, y, mask, w, 5e-5)) <= TOL
+    assert net.accuracy(shifts, inputs, y, mask, n_nbrs) == so.accuracy_from_preds(out, y, mask, n_nbrs)
+    rev = [readout, cfg1["rev_last_nodes"][sel], cfg1["rev_flows"][sel]]
+    out_r = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, rev[1], rev[2])
+    assert abs(net.loss(net.weights, rev, cfg1["rev_targets"][sel], mask)
+               - so.loss_from_preds(out_r, cfg1["rev_targets"][sel], mask, w, 5e-5)) <= TOL
+
+
+def test_larger_synthetic_complex_against_csr_oracle():
+    """E ~ 13k synthetic complex (own generator), hidden 32, oracle run with scipy CSR shifts."""
+    _need_gpu()
+    import scipy.sparse as sp
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(5000)
+    sc = SimplicialComplex(cx)
+    paths = g.generate_random_walks(cx, m=12, seed=5)
+    flows, choice, last, tnodes, _ = g.path_dataset(cx, paths, seed=2)
+    D = sc.max_degree
+    y = so.onehot_targets(choice, D)
+    shapes = so.weight_shapes(1, [(3, 32)] * 3, 1)
+    w = _rand_weights(shapes, 0.15, 21)
+    B1, B2 = g.incidence_matrices(cx)
+    L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+    B1x = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()
+    Bc = lambda n: B1x[sc.nbrhoods[n]].toarray()
+    X = flows.todense().astype(np.float64)
+    mask = np.ones(len(paths), int)
+    ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, Bc, last, X, y, mask, 0.0)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.scone_func(wt, *shifts, readout, last, flows)
+    loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / len(paths)
+    loss.backward()
+    assert abs(float(loss) - ref_loss) <= TOL
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL
+
+
+def test_errors_are_loud(cfg1, sc1):
+    from scone_gcn_amd import trajectory_experiments as te
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    w = _rand_weights(so.weight_shapes(1, [(3, 16)] * 3, 1), 0.1, 1)
+    with pytest.raises(AssertionError):
+        te.scone_func(w[:-2], *shifts, readout, cfg1["last_nodes"][:4], cfg1["flows"][:4])   # wrong number of weights
+    with pytest.raises(ValueError):
+        te.scone_func(w, *shifts, readout, cfg1["last_nodes"][:3], cfg1["flows"][:4])
