@@ -68,6 +68,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: its bundled libamdhip64.so.7 then serves both torch and this library, so the
+    # device pointers and streams torch hands us belong to the same HIP runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run scone_gcn_amd/csrc/build.sh "

@@ -36,7 +36,10 @@ def _rand_weights(shapes, scale, seed):
 
 
 def _maxdiff(a, b):
-    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+    """max |a - b| in units of max(1, max|b|): the 1e-5 bar is absolute for O(1) log-probabilities / gradients and
+    relative to the reference's magnitude when that is larger (fp32 carries ~7 digits)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b))))
 
 
 def _oracle_scone(cfg1, weights, sel, model, flips=None):
@@ -57,7 +60,7 @@ def test_forward_and_gradients_match_oracle(cfg1, sc1, model, hidden):
     from scone_gcn_amd import trajectory_experiments as te
     sel = np.arange(0, 27)            # not a multiple of the slab width on purpose
     shapes = so.weight_shapes(1, [(3, hidden)] * 3, 1)
-    w = _rand_weights(shapes, 0.25, 7)
+    w = _rand_weights(shapes, 0.25 if model == "scone" else 0.03, 7)   # ebli: L1^2 entries reach 31, keep outputs O(1)
     shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, model)
     y, last = cfg1["targets"][sel], cfg1["last_nodes"][sel]
     mask = np.ones(len(sel), int)
@@ -75,7 +78,7 @@ def test_forward_and_gradients_match_oracle(cfg1, sc1, model, hidden):
     yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
     loss = -(out[m] * yt[m]).sum() / m.sum()
     loss.backward()
-    assert abs(float(loss) - ref_loss) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
 
@@ -114,6 +117,8 @@ def test_flip_invariance_tanh(cfg1, sc1):
     last = cfg1["last_nodes"][sel]
     outs = {}
     for model in ("scone", "ebli"):
+        if model == "ebli":
+            w = _rand_weights(shapes, 0.03, 9)
         for flip in (False, True):
             shifts, readout, flips = te.setup_from_complex(sc1, model, flip_edges=flip)
             X = te.apply_flips(cfg1["flows"][sel], flips)
@@ -121,6 +126,7 @@ def test_flip_invariance_tanh(cfg1, sc1):
     assert _maxdiff(outs[("scone", False)], outs[("scone", True)]) <= TOL
     assert _maxdiff(outs[("ebli", False)], outs[("ebli", True)]) > 1e-4
     # and the flipped scone path matches the oracle run on flipped operators
+    w = _rand_weights(shapes, 0.25, 9)
     flips = sc1.flip_vector(1)
     assert np.array_equal(np.diag(so.flip_matrix(cfg1["E"])), flips)
     shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, "scone", flips)
@@ -150,7 +156,7 @@ def test_bunch_matches_oracle(cfg1, sc1, hidden):
     yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
     loss = -(out[m] * yt[m]).sum() / m.sum()
     loss.backward()
-    assert abs(float(loss) - ref_loss) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
 
@@ -184,7 +190,7 @@ def test_trainer_step_matches_oracle_adam(cfg1, sc1):
     net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, train_mask, model_type="scone")
     w0 = so.generate_weights(1, [(3, 16)] * 3, 1)
     for a, b in zip(net.weights, w0):
-        assert _maxdiff(a.cpu().numpy(), b) <= 1e-9          # same seed-1030 stream as STM:15, 237
+        assert np.array_equal(a.cpu().numpy(), b.astype(np.float32))   # same seed-1030 stream as STM:15, 237
     shifts_o, Bc, _, act = _oracle_scone(cfg1, w0, sel, "scone")
     adam = so.Adam([w.astype(np.float32).astype(np.float64) for w in w0], 1e-3)
     rs_o = np.random.RandomState(1030)
@@ -253,7 +259,7 @@ def test_larger_synthetic_complex_against_csr_oracle():
     out = te.scone_func(wt, *shifts, readout, last, flows)
     loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / len(paths)
     loss.backward()
-    assert abs(float(loss) - ref_loss) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL
 
