@@ -352,7 +352,7 @@ int scn_conv_n_slots(scn_conv_t c) { return c ? c->n_slots : SCN_ERR_BAD_ARG; }
 
 int scn_conv_plan_info(scn_conv_t c, int32_t* n_blocks, float* mean_sources_per_row) {
     if (!c) return SCN_ERR_BAD_ARG;
-    if (n_blocks) *n_blocks = c->plan.built ? c->plan.n_blocks : 0;
+    if (n_blocks) *n_blocks = c->plan.built ? c->plan.dev.n_blocks : 0;
     if (mean_sources_per_row) *mean_sources_per_row = c->plan.built ? (float)c->plan.mean_src_per_row : 0.f;
     return SCN_OK;
 }

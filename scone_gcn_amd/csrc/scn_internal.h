@@ -61,22 +61,34 @@ struct Group {
     std::vector<float> h_val0, h_val1;
 };
 
-// LDS-blocked execution plan of a single-group operator (see scn_blocked.hip)
+// ---- LDS-blocked execution plan of a single-group operator (scn_blocked.hip) ----
+constexpr int BK_R = 32;        // output rows per block (upper bound; 8 per wave)
+constexpr int BK_SRC = 96;      // staged source pieces per block (upper bound)
+constexpr int BK_NS = 4;        // trajectories per slab the blocked kernels are built for
+constexpr int BK_THREADS = 256;
+constexpr int BK_MAXW = 96;     // widest ELL row a block may carry
+
+// device view passed to kernels by value
+struct PlanDev {
+    int32_t n_blocks, ell_w_max;
+    const int32_t* blk_row0;    // [n_blocks] first output row
+    const uint8_t* blk_rows;    // [n_blocks] rows in block (<= BK_R)
+    const int32_t* src_ptr;     // [n_blocks+1]
+    const int32_t* src_rows;    // staged source rows, ascending within a block
+    const int32_t* ell_ptr;     // [n_blocks] entry offset (entries are [t][BK_R])
+    const uint8_t* width;       // [n_blocks] padded entries per row
+    const uint8_t* tile_w;      // [n_blocks][4] entries needed by each wave's 8 rows
+    const uint8_t* ell_slot;    // local slot of entry
+    const float* ell_v0;
+    const float* ell_v1;
+    const uint8_t* self_slot;   // [n_blocks][BK_R] slot of the row itself (identity shift)
+};
+
 struct BlockPlan {
     bool built = false;
-    int32_t n_blocks = 0;
-    int32_t max_rows = 0;      // rows per block upper bound (R)
-    int32_t max_src = 0;       // staged source pieces per block upper bound
-    int32_t ell_width = 0;     // padded entries per row
+    PlanDev dev{};
     double mean_src_per_row = 0.0;
-    int32_t* d_blk_row0 = nullptr;   // [n_blocks+1]
-    int32_t* d_src_ptr = nullptr;    // [n_blocks+1]
-    int32_t* d_src_rows = nullptr;   // [src_ptr[n_blocks]] global source row ids, ascending within a block
-    // ELL entries, per block [ell_width][max_rows]: local slot (uint16 in low bits) and two values
-    uint16_t* d_ell_slot = nullptr;
-    float* d_ell_v0 = nullptr;
-    float* d_ell_v1 = nullptr;
-    uint16_t* d_self_slot = nullptr; // [n_blocks][max_rows] slot of the row itself (identity term), 0xFFFF if absent
+    std::vector<void*> allocs;
 };
 
 }  // namespace scn

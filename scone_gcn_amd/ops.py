@@ -16,6 +16,44 @@ from .synthetic_data_gen import SparseFlows
 NS = 4   # trajectories per slab
 
 
+class KernelTimer:
+    """Optional per-call timing with events on the launch stream (torch's current stream), used by bench.py to get
+    the average duration of one kernel family live.  Disabled (None) by default: no events, no overhead."""
+    active = None
+
+    def __init__(self):
+        self.records = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.records.items()}
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        t = KernelTimer.active
+        if t is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *a):
+        t = KernelTimer.active
+        if t is not None:
+            self.b.record()
+            t.records.setdefault(self.key, []).append((self.a, self.b))
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -89,9 +127,10 @@ class ConvOp:
             assert tuple(w.shape) == (c_in[self.slot_group[s]], c_out), "weight shape"
         if out is None:
             out = torch.empty((S, self.n_rows, ns, c_out), device=srcs[0].device, dtype=torch.float32)
-        check(lib.scn_conv_forward(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
-                                   ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out), _stream()),
-              "scn_conv_forward")
+        with _timed("conv_fwd c%s->%d" % ("+".join(map(str, c_in)), c_out)):
+            check(lib.scn_conv_forward(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
+                                       ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out), _stream()),
+                  "scn_conv_forward")
         return out
 
     def backward(self, dzs, Ws, aux, act, need_dx, dWs):
@@ -109,11 +148,12 @@ class ConvOp:
         nbytes = lib.scn_conv_backward_workspace(self.handle, S, ns, cdz, c_aux)
         ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
         dx = torch.empty_like(aux) if need_dx else None
-        check(lib.scn_conv_backward(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
-                                    ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
-                                    _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
-                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-              "scn_conv_backward")
+        with _timed("conv_bwd c%s->%d%s" % ("+".join(map(str, c_dz)), c_aux, "" if need_dx else " (dW only)")):
+            check(lib.scn_conv_backward(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
+                                        ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
+                                        _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
+                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                  "scn_conv_backward")
         return dx
 
     def spmm_dual(self, x, dual=True):
@@ -122,8 +162,9 @@ class ConvOp:
         assert rows == self.group_cols[0]
         ya = torch.empty((S, self.n_rows, k), device=x.device, dtype=torch.float32)
         yb = torch.empty_like(ya) if dual else None
-        check(lib.scn_spmm_dual(self.handle, S, k, _dev(x), _dev(ya), _dev(yb) if dual else None, _stream()),
-              "scn_spmm_dual")
+        with _timed("spmm_dual k%d" % k if dual else "spmm k%d" % k):
+            check(lib.scn_spmm_dual(self.handle, S, k, _dev(x), _dev(ya), _dev(yb) if dual else None, _stream()),
+                  "scn_spmm_dual")
         return ya, yb
 
 

@@ -179,28 +179,52 @@ class Scone_GCN():
         return float((np.sum(t > r) + 0.5 * np.sum(t == r)) / np.sum(m))
 
     # ------------------------------------------------------------------ gradient step (STM:306-310)
-    def _accumulate_grad(self, plan, inputs, y, idx, total):
-        """flat_g += d/dW of  -sum_{n in idx} <logp_n, y_n> / total, micro-batched.  Returns that partial loss as a
-        0-dim device tensor (no host synchronisation inside the step)."""
+    def stage(self, inputs, y, idx):
+        """Move trajectories idx to the device as micro-batches of flow slabs: list of (x, last_nodes, y) with
+        x [S, E, ns, 1] fp32, last_nodes [S*ns] int32, y [S*ns, D] fp32 (zero rows for padding)."""
+        plan = self._plan(inputs)
         device = self._flat_w.device
         k = 7 if self.model_type == 'bunch' else 3
         widths = [1] + [self._shapes[k * i][1] for i in range(len(self._shapes) // k)]
         rows = sum(plan.sizes) if self.model_type == 'bunch' else plan.n_edges
         mb = ops.micro_batch_size(rows, widths, len(idx), device=device)
-        part = torch.zeros((), device=device, dtype=torch.float64)
+        staged = []
         for c0 in range(0, len(idx), mb):
             sel = idx[c0:c0 + mb]
             sub = _select(inputs, sel)
             x, n = ops.flows_to_slabs(sub[2], plan.layout, device)
             last_dev = ops._last_nodes_dev(sub[1], x.shape[0] * ops.NS, device)
-            logp, saved = plan.forward(x, last_dev, self.weights)
-            yt = torch.zeros((x.shape[0] * ops.NS, logp.shape[1]), device=device, dtype=torch.float32)
+            D = np.asarray(y).shape[1]
+            yt = torch.zeros((x.shape[0] * ops.NS, D), device=device, dtype=torch.float32)
             yt[:n] = torch.as_tensor(np.asarray(y)[sel], dtype=torch.float32).reshape(n, -1).to(device)
+            staged.append((x, last_dev, yt))
+        return staged
+
+    def _accumulate_staged(self, plan, staged, total):
+        """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches.  Returns that partial loss
+        as a 0-dim device tensor (no host synchronisation inside the step)."""
+        part = torch.zeros((), device=self._flat_w.device, dtype=torch.float64)
+        for x, last_dev, yt in staged:
+            logp, saved = plan.forward(x, last_dev, self.weights)
             d_logp = yt * (-1.0 / total)
             part += (logp.double() * d_logp.double()).sum()
             plan.backward(saved, logp, d_logp, last_dev, self.weights, self._grads)
             del saved
         return part
+
+    def _accumulate_grad(self, plan, inputs, y, idx, total):
+        return self._accumulate_staged(plan, self.stage(inputs, y, idx), total)
+
+    def grad_step_staged(self, inputs, staged, total, apply=True):
+        """grad_step on micro-batches already resident on the device (this rank's shard); `total` is the GLOBAL
+        number of trajectories in the batch (all ranks)."""
+        plan = self._plan(inputs)
+        self._flat_g.zero_()
+        loss = self._accumulate_staged(plan, staged, total)
+        dp.all_reduce_sum_(self._flat_g, self.process_group)
+        if apply:
+            self._adam()
+        return loss
 
     def grad_step(self, inputs, y, batch_mask, apply=True):
         """One optimiser step on the masked batch: gradient of self.loss (STM:307) + Adam update (STM:310, 326).

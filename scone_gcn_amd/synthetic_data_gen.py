@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 import scipy.sparse as sp
-from scipy.sparse.csgraph import breadth_first_order
+from scipy.sparse.csgraph import breadth_first_order, dijkstra
 from scipy.spatial import Delaunay
 
 
@@ -124,10 +124,12 @@ def _tree_path(pred, root, v):
     return out[::-1]
 
 
-def generate_random_walks(cx, m=1000, seed=1030, waypoint_pool=None):
+def generate_random_walks(cx, m=1000, seed=1030, waypoint_pool=None, metric="hops"):
     """SDG:178-243.  `waypoint_pool=k` draws the A_r / B_r waypoints from k candidates per region so that
-    only 6k BFS trees are built however many walks are requested (needed at |V| ~ 4e5); None = fresh draw
-    per walk as the reference does."""
+    only 6k shortest-path trees are built however many walks are requested (needed at |V| ~ 4e5); None = fresh
+    draw per walk as the reference does.  metric="hops" is the reference's BFS shortest path; "euclid" weights
+    edges by length (Dijkstra): on very large Delaunay complexes the hop-count paths all detour along the long
+    convex-hull edges, overlap there and fail the reference's simple-path test (SDG:239) almost always."""
     rs = np.random.RandomState(seed)
     pts, valid = cx.coords, cx.valid_idxs
     s = np.sum(pts[valid], axis=1)
@@ -143,11 +145,19 @@ def generate_random_walks(cx, m=1000, seed=1030, waypoint_pool=None):
         A = [rs.choice(a, size=min(waypoint_pool, len(a)), replace=False) for a in A]
         B = [rs.choice(b, size=min(waypoint_pool, len(b)), replace=False) for b in B]
     G = adjacency(cx)
+    if metric == "euclid":
+        a, b = cx.edges[:, 0], cx.edges[:, 1]
+        w = np.linalg.norm(pts[a] - pts[b], axis=1)
+        G = sp.csr_matrix((np.concatenate([w, w]), (np.concatenate([a, b]), np.concatenate([b, a]))),
+                          shape=(cx.n_nodes, cx.n_nodes))
     trees = {}
 
     def tree(v):
         if v not in trees:
-            trees[v] = breadth_first_order(G, v, directed=False, return_predecessors=True)[1]
+            if metric == "euclid":
+                trees[v] = dijkstra(G, directed=False, indices=v, return_predecessors=True)[1]
+            else:
+                trees[v] = breadth_first_order(G, v, directed=False, return_predecessors=True)[1]
         return trees[v]
 
     paths, i, tries = [], 0, 0
