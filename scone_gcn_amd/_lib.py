@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscone_hip.so")
+LIB_PATH = os.environ.get("SCN_LIB_PATH") or os.path.join(_HERE, "libscone_hip.so")   # override: diagnostic builds only
 
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 c_void_p, c_size_t = ctypes.c_void_p, ctypes.c_size_t

@@ -2,18 +2,21 @@
 // pattern (slots: identity, S_lower, S_upper), ns = 4, channel widths 16 or 32 (MFMA) and 1 (first layer).
 //
 // Execution plan (built once per operator on the host, build_block_plan):
-//   the output rows are cut into blocks of <= 32 consecutive rows whose gather sources (<= 96 distinct source
+//   the output rows are cut into blocks of <= 64 consecutive rows whose gather sources (<= 128 distinct source
 //   rows) are staged once per slab into LDS; the block's CSR slice is re-expressed as a padded ELL tile with
 //   LOCAL source slots (uint8) so the inner loop touches LDS only.  Rows are expected in a locality order
-//   (Hilbert order of the edge midpoints, scone_gcn_amd/complex.py) so a block's sources are ~2.5x its rows.
+//   (Hilbert order of the edge midpoints, scone_gcn_amd/complex.py) so a block's sources are ~2x its rows.
 //
-// Kernel structure (per workgroup of 4 waves, grid-strided over blocks with an XCD-contiguous mapping):
-//   for block: load ELL tile + source list -> LDS
-//     for slab: stage source pieces (16-B coalesced loads -> XOR-swizzled LDS image) | barrier |
-//               each wave gathers its 8 rows x 4 trajectories with lane = (point, channel slice) and feeds the
-//               gathered [self | lower | upper] vectors straight into f32 MFMA against weights held in registers |
-//               activation epilogue + store | barrier
+// Kernel structure: one 8-wave workgroup per CU, grid-strided over blocks with an XCD-contiguous mapping.
+//   for block: ELL tile + source list -> LDS
+//     for slab: [s_waitcnt vmcnt(0); s_barrier]  -> slab s has landed in buffer s&1, everybody left buffer (s+1)&1
+//               issue LDS-DMA (global_load_lds, 16 B/lane, per-lane source = gather) of slab s+1 into the other buffer
+//               compute slab s: each wave gathers its 8 rows x 4 trajectories with lane = (point, channel slice)
+//               from the XOR-swizzled LDS image and feeds [self | lower | upper] straight into f32 MFMA against
+//               weights held in registers; the activation epilogue's stores are deferred by one slab so the next
+//               vmcnt(0) never waits on stores that were just issued.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -23,6 +26,21 @@ namespace scn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- diagnostic build only (-DSCN_STAMPS): per-segment cycle sums of fwd_c32, never compiled into the product
+#ifdef SCN_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned long long t0_ = 0, t1_ = 0, acc_[6] = {0, 0, 0, 0, 0, 0}
+#define STAMP_ADD(i) do { STAMP(t1_); acc_[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#define STAMP_START() STAMP(t0_)
+#define STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_stamps[i_], acc_[i_]); atomicAdd(&g_stamps[7], 1ull); } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_ADD(i)
+#define STAMP_START()
+#define STAMP_FLUSH()
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -53,7 +71,7 @@ int build_block_plan(scn_conv_s* c) {
     const int n_rows = c->n_rows;
     std::vector<int32_t> blk_row0, src_ptr(1, 0), src_rows, ell_ptr;
     std::vector<uint8_t> blk_rows, width, tile_w, ell_slot, self_slot;
-    std::vector<float> ell_v0, ell_v1;
+    std::vector<float2> ell_v;
     std::vector<int32_t> mark(G.n_cols, -1), local(G.n_cols, 0), cur;
     cur.reserve(BK_SRC + 64);
     int64_t total_src = 0;
@@ -72,8 +90,8 @@ int build_block_plan(scn_conv_s* c) {
             for (int j = j0; j < j1 && self_new; ++j)
                 if (G.h_col[j] == r) self_new = false;
             if (self_new) ++add;
-            const int nw = std::max(w, j1 - j0);
-            if ((int)cur.size() + add > BK_SRC || nw > BK_MAXW) break;
+            const int nw = std::max(w, (j1 - j0 + 1) & ~1);          // padded width, even
+            if ((int)cur.size() + add > BK_SRC || nw * (rows + 1) > BK_ELL_CAP || nw > 254) break;
             for (int j = j0; j < j1; ++j)
                 if (mark[G.h_col[j]] != bid) { mark[G.h_col[j]] = bid; cur.push_back(G.h_col[j]); }
             if (mark[r] != bid) { mark[r] = bid; cur.push_back(r); }
@@ -90,28 +108,27 @@ int build_block_plan(scn_conv_s* c) {
         ell_ptr.push_back((int32_t)ell_slot.size());
         width.push_back((uint8_t)w);
         wmax = std::max(wmax, w);
-        const size_t base = ell_slot.size();
-        ell_slot.resize(base + (size_t)w * BK_R, 0);
-        ell_v0.resize(base + (size_t)w * BK_R, 0.f);
-        ell_v1.resize(base + (size_t)w * BK_R, 0.f);
-        uint8_t tw[4] = {0, 0, 0, 0};
+        const size_t base = ell_slot.size();                 // entries are [row][w], w even, zero padded
+        ell_slot.resize(base + (size_t)w * rows, 0);
+        ell_v.resize(base + (size_t)w * rows, float2{0.f, 0.f});
+        uint8_t tw[BK_WAVES];
+        for (int i = 0; i < BK_WAVES; ++i) tw[i] = 0;
         for (int i = 0; i < BK_R; ++i) {
             uint8_t ss = 0;
             if (i < rows) {
                 const int r = r0 + i;
                 const int j0 = G.h_rowptr[r], j1 = G.h_rowptr[r + 1];
                 for (int j = j0; j < j1; ++j) {
-                    const size_t e = base + (size_t)(j - j0) * BK_R + i;
+                    const size_t e = base + (size_t)i * w + (j - j0);
                     ell_slot[e] = (uint8_t)local[G.h_col[j]];
-                    ell_v0[e] = G.h_val0[j];
-                    ell_v1[e] = G.h_val1[j];
+                    ell_v[e] = float2{G.h_val0[j], G.h_val1[j]};
                 }
-                tw[i >> 3] = std::max<uint8_t>(tw[i >> 3], (uint8_t)(j1 - j0));
+                tw[i >> 3] = std::max<uint8_t>(tw[i >> 3], (uint8_t)((j1 - j0 + 1) & ~1));
                 ss = (uint8_t)local[r];
             }
             self_slot.push_back(ss);
         }
-        tile_w.insert(tile_w.end(), tw, tw + 4);
+        tile_w.insert(tile_w.end(), tw, tw + BK_WAVES);
         total_src += (int64_t)cur.size();
         r0 += rows;
         ++bid;
@@ -128,8 +145,7 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, width, &P.dev.width)) != SCN_OK) return st;
     if ((st = upload(c, tile_w, &P.dev.tile_w)) != SCN_OK) return st;
     if ((st = upload(c, ell_slot, &P.dev.ell_slot)) != SCN_OK) return st;
-    if ((st = upload(c, ell_v0, &P.dev.ell_v0)) != SCN_OK) return st;
-    if ((st = upload(c, ell_v1, &P.dev.ell_v1)) != SCN_OK) return st;
+    if ((st = upload(c, ell_v, &P.dev.ell_v)) != SCN_OK) return st;
     if ((st = upload(c, self_slot, &P.dev.self_slot)) != SCN_OK) return st;
     P.mean_src_per_row = (double)total_src / std::max(1, n_rows);
     P.built = true;
@@ -137,35 +153,35 @@ int build_block_plan(scn_conv_s* c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared device helpers
+// LDS layout and pipeline helpers
 // ------------------------------------------------------------------------------------------------
-// LDS carve: [stage: BK_SRC * PIECE bytes][v0: BK_R*wmax f32][v1: same][srcrows: BK_SRC i32][slot: BK_R*wmax u8][self: BK_R u8]
+// [buf0: BK_SRC*PIECE][buf1: BK_SRC*PIECE][ell_v: BK_ELL_CAP float2][srcrows: BK_SRC i32][slot: BK_ELL_CAP u8][self: BK_R u8][extra]
 struct Smem {
-    char* stage;
-    float* v0;
-    float* v1;
+    char* buf0;
+    int buf_stride;
+    __device__ __forceinline__ char* buf(int i) const { return buf0 + i * buf_stride; }
+    float2* v;
     int32_t* srcrows;
     uint8_t* slot;
     uint8_t* self;
 };
-__device__ __forceinline__ Smem carve(char* base, int piece, int wmax) {
-    Smem s;
-    s.stage = base;
-    s.v0 = (float*)(base + BK_SRC * piece);
-    s.v1 = s.v0 + BK_R * wmax;
-    s.srcrows = (int32_t*)(s.v1 + BK_R * wmax);
-    s.slot = (uint8_t*)(s.srcrows + BK_SRC);
-    s.self = s.slot + BK_R * wmax;
-    return s;
-}
-__host__ __device__ static inline size_t smem_bytes(int piece, int wmax, int extra = 0) {
-    size_t b = (size_t)BK_SRC * piece + (size_t)BK_R * wmax * 9 + BK_SRC * 4 + BK_R;
+__host__ __device__ static inline size_t smem_bytes(int piece, int extra = 0) {
+    size_t b = (size_t)2 * BK_SRC * piece + (size_t)BK_ELL_CAP * 9 + BK_SRC * 4 + BK_R;
     return ((b + 15) / 16) * 16 + extra;
+}
+__device__ __forceinline__ Smem carve(char* base, int piece) {
+    Smem s;
+    s.buf0 = base;
+    s.buf_stride = BK_SRC * piece;
+    s.v = (float2*)(base + 2 * BK_SRC * piece);
+    s.srcrows = (int32_t*)(s.v + BK_ELL_CAP);
+    s.slot = (uint8_t*)(s.srcrows + BK_SRC);
+    s.self = s.slot + BK_ELL_CAP;
+    return s;
 }
 
 struct BlockMeta { int row0, rows, nsrc, w; };
 
-// loads the block's ELL tile / source list into LDS (caller brackets with barriers)
 __device__ __forceinline__ BlockMeta load_block(const PlanDev& P, int b, const Smem& sm) {
     BlockMeta m;
     m.row0 = P.blk_row0[b];
@@ -175,35 +191,76 @@ __device__ __forceinline__ BlockMeta load_block(const PlanDev& P, int b, const S
     m.w = P.width[b];
     const int ep = P.ell_ptr[b];
     for (int i = threadIdx.x; i < m.nsrc; i += BK_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
-    for (int i = threadIdx.x; i < m.w * BK_R; i += BK_THREADS) {
+    for (int i = threadIdx.x; i < m.w * m.rows; i += BK_THREADS) {
         sm.slot[i] = P.ell_slot[ep + i];
-        sm.v0[i] = P.ell_v0[ep + i];
-        sm.v1[i] = P.ell_v1[ep + i];
+        sm.v[i] = P.ell_v[ep + i];
     }
     if (threadIdx.x < BK_R) sm.self[threadIdx.x] = P.self_slot[(size_t)b * BK_R + threadIdx.x];
     return m;
 }
 
-// XOR swizzle of the 16-byte chunk index inside a staged piece (keeps the lane=(point, channel slice) gather
-// spread over the LDS banks): 512-B pieces (C=32): chunk = n*8 + h*4 + q ; 256-B pieces (C=16): chunk = n*4 + g.
+// two consecutive ELL entries of a row: slots and (val0, val1) pairs, one 2-byte and one 16-byte LDS read
+struct EllPair { int s0, s1; f32x4 v; };
+__device__ __forceinline__ EllPair ell_load(const Smem& sm, int idx) {
+    EllPair e;
+    const uint32_t ss = *(const uint16_t*)(sm.slot + idx);
+    e.s0 = ss & 255;
+    e.s1 = ss >> 8;
+    e.v = *(const f32x4*)(sm.v + idx);
+    return e;
+}
+
+// XOR swizzle of the 16-byte chunk index inside a staged piece (involution for a fixed slot): keeps the
+// lane = (point, channel slice) gather spread over the LDS banks.
+//   512-B pieces (C=32): chunk = n*8 + h*4 + q ; 256-B pieces (C=16): chunk = n*4 + g.
 __device__ __forceinline__ int swz32(int slot, int chunk) {
     return chunk ^ ((((slot >> 1) & 1) << 2) | ((slot & 1) << 1) | ((chunk >> 4) & 1));
 }
 __device__ __forceinline__ int swz16(int slot, int chunk) { return chunk ^ (slot & 3); }
 
-// stage nsrc pieces of PIECE bytes of slab-base Xs into LDS (coalesced 16-B loads)
+// LDS-DMA of nsrc pieces of slab-base Xs into buf: LDS image is lane-linear, the swizzle goes on the SOURCE chunk.
 template <int PIECE, int SWZ>
-__device__ __forceinline__ void stage_pieces(const char* Xs, const Smem& sm, int nsrc) {
+__device__ __forceinline__ void dma_stage(const char* Xs, char* buf, const Smem& sm, int nsrc) {
     constexpr int CPP = PIECE / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = nsrc * CPP;
-    for (int c = threadIdx.x; c < total; c += BK_THREADS) {
-        const int slot = c / CPP, ch = c % CPP;
-        const f32x4 v = *(const f32x4*)(Xs + (size_t)sm.srcrows[slot] * PIECE + ch * 16);
-        int pos = ch;
-        if (SWZ == 32) pos = swz32(slot, ch);
-        if (SWZ == 16) pos = swz16(slot, ch);
-        *(f32x4*)(sm.stage + slot * PIECE + pos * 16) = v;
+    for (int base = wave * 64; base < total; base += BK_THREADS) {
+        const int c = base + lane;
+        if (c < total) {
+            const int slot = c / CPP, pos = c % CPP;
+            int d = pos;
+            if (SWZ == 32) d = swz32(slot, pos);
+            if (SWZ == 16) d = swz16(slot, pos);
+            const char* g = Xs + (size_t)sm.srcrows[slot] * PIECE + d * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+        }
     }
+}
+// runtime piece size (dual SpMM), no swizzle
+__device__ __forceinline__ void dma_stage_rt(const char* Xs, char* buf, const Smem& sm, int nsrc, int piece, int cpp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = nsrc * cpp;
+    for (int base = wave * 64; base < total; base += BK_THREADS) {
+        const int c = base + lane;
+        if (c < total) {
+            const int slot = c / cpp, pos = c - slot * cpp;
+            const char* g = Xs + (size_t)sm.srcrows[slot] * piece + pos * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void wait_all_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // XCD-contiguous block range of this workgroup: blocks b = first, first+stride, ... < last
@@ -215,21 +272,178 @@ __device__ __forceinline__ void block_range(int n_blocks, int& first, int& last,
     first = b0 + j;
 }
 
+#define SCN_SLAB_RANGE() \
+    const int slab0 = (int)((int64_t)blockIdx.y * n_slabs / gridDim.y), slab1 = (int)((int64_t)(blockIdx.y + 1) * n_slabs / gridDim.y)
+
+// ------------------------------------------------------------------------------------------------
+// dual SpMM on K-float pieces (K % 4 == 0, K <= 128): ya = val0-operator * x, yb = val1-operator * x
+// 16 waves per workgroup (no MFMA, few registers): thread = (row, 16-byte chunk), two items per thread;
+// results are stored one slab late so the per-slab vmcnt(0) never waits on fresh stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_THREADS = 1024;
+constexpr int SP_ITEMS = 2;           // BK_R * 32 chunks / SP_THREADS
+
+__device__ __forceinline__ void dma_stage_sp(const char* Xs, char* buf, const Smem& sm, int nsrc, int piece, int cpp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = nsrc * cpp;
+    for (int base = wave * 64; base < total; base += SP_THREADS) {
+        const int c = base + lane;
+        if (c < total) {
+            const int slot = c / cpp, pos = c - slot * cpp;
+            const char* g = Xs + (size_t)sm.srcrows[slot] * piece + pos * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+        }
+    }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, const float* __restrict__ X,
+                                                                     float* __restrict__ ya, float* __restrict__ yb,
+                                                                     int n_rows, int n_cols, int n_slabs, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int piece = K * 4, cpp = K / 4;
+    const Smem sm = carve(smem, piece);
+    uint8_t* tws = (uint8_t*)(smem + smem_bytes(piece));           // [BK_WAVES] per-row-group widths
+    int b, b_end, b_stride;
+    block_range(P.n_blocks, b, b_end, b_stride);
+    SCN_SLAB_RANGE();
+    if (slab0 >= slab1) return;
+    f32x4 pa[SP_ITEMS], pb[SP_ITEMS];
+    size_t pend_off = 0;
+    int pend_total = -1;
+    for (; b < b_end; b += b_stride) {
+        wait_all_and_barrier();
+        BlockMeta m;
+        {   // load_block with this kernel's thread count
+            m.row0 = P.blk_row0[b];
+            m.rows = P.blk_rows[b];
+            const int sp0 = P.src_ptr[b];
+            m.nsrc = P.src_ptr[b + 1] - sp0;
+            m.w = P.width[b];
+            const int ep = P.ell_ptr[b];
+            for (int i = threadIdx.x; i < m.nsrc; i += SP_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
+            for (int i = threadIdx.x; i < m.w * m.rows; i += SP_THREADS) {
+                sm.slot[i] = P.ell_slot[ep + i];
+                sm.v[i] = P.ell_v[ep + i];
+            }
+            if (threadIdx.x < BK_WAVES) tws[threadIdx.x] = P.tile_w[b * BK_WAVES + threadIdx.x];
+        }
+        __syncthreads();
+        const int total = m.rows * cpp;
+        dma_stage_sp((const char*)X + (size_t)slab0 * n_cols * piece, sm.buf(0), sm, m.nsrc, piece, cpp);
+        for (int slab = slab0; slab < slab1; ++slab) {
+            const int cur_off = ((slab - slab0) & 1) * sm.buf_stride;
+            wait_vm_and_barrier();
+            if (slab + 1 < slab1)
+                dma_stage_sp((const char*)X + (size_t)(slab + 1) * n_cols * piece, sm.buf((slab + 1 - slab0) & 1), sm, m.nsrc,
+                             piece, cpp);
+            if (pend_total >= 0) {
+#pragma unroll
+                for (int k = 0; k < SP_ITEMS; ++k) {
+                    const int idx = threadIdx.x + k * SP_THREADS;
+                    if (idx < pend_total) {
+                        *(f32x4*)(ya + pend_off + (size_t)idx * 4) = pa[k];
+                        if (DUAL) *(f32x4*)(yb + pend_off + (size_t)idx * 4) = pb[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SP_ITEMS; ++k) {
+                const int idx = threadIdx.x + k * SP_THREADS;
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                if (idx < total) {
+                    const int r = idx / cpp, ch = idx - r * cpp;
+                    const int tw = __builtin_amdgcn_readfirstlane(tws[r >> 3]);   // a wave's lanes share the row group
+                    const int rb = r * m.w;
+                    const char* cbase = sm.buf0 + cur_off + ch * 16;
+#pragma unroll 2
+                    for (int t = 0; t < tw; t += 2) {
+                        const EllPair e = ell_load(sm, rb + t);
+                        const f32x4 d0 = *(const f32x4*)(cbase + e.s0 * piece);
+                        const f32x4 d1 = *(const f32x4*)(cbase + e.s1 * piece);
+                        a0 += e.v[0] * d0;
+                        if (DUAL) a1 += e.v[1] * d0;
+                        a0 += e.v[2] * d1;
+                        if (DUAL) a1 += e.v[3] * d1;
+                    }
+                }
+                pa[k] = a0;
+                pb[k] = a1;
+            }
+            pend_off = ((size_t)slab * n_rows + m.row0) * K;
+            pend_total = total;
+        }
+    }
+    if (pend_total >= 0) {
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; ++k) {
+            const int idx = threadIdx.x + k * SP_THREADS;
+            if (idx < pend_total) {
+                *(f32x4*)(ya + pend_off + (size_t)idx * 4) = pa[k];
+                if (DUAL) *(f32x4*)(yb + pend_off + (size_t)idx * 4) = pb[k];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, C_in = C_out = 32   (v_mfma_f32_32x32x2_f32; lane = (point p = lane&31, channel half h = lane>>5))
+// (f32 MFMA and VALU do not overlap on a gfx950 SIMD -- tools/ubench/mfma_valu_overlap.hip -- so the waves are not
+// staggered; what does overlap with the MFMA chain is vector-memory issue, see c32_mfma_epilogue.)
 // ------------------------------------------------------------------------------------------------
+// out^T tile = W^T Z^T: the MFMA takes the weights as A and the gathered point vectors as B, so the accumulator
+// has the POINT on the lane and 16 channels in registers -> the epilogue stores four 16-byte chunks per lane.
+//   D[i = channel][j = point]: lane (p, h) holds channels (r&3) + 8*(r>>2) + 4*h, r = 0..15, of point p.
+template <int ACT, typename Side>
+__device__ __forceinline__ void c32_mfma_epilogue(const f32x4 (&zs)[4], const f32x4 (&zl)[4], const f32x4 (&zu)[4],
+                                                  const float (&Bw)[3][16], f32x16& pend, Side&& side) {
+    // `side(k)` (k = 0..11) issues one independent vector-memory instruction after every 4th MFMA: the wave would sit
+    // on the accumulator dependency anyway, so the memory pipe's address processing hides under the MFMA chain.
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[0][s], zs[s >> 2][s & 3], acc, 0, 0, 0);
+        if ((s & 3) == 3) side(s >> 2);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[1][s], zl[s >> 2][s & 3], acc, 0, 0, 0);
+        if ((s & 3) == 3) side(4 + (s >> 2));
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[2][s], zu[s >> 2][s & 3], acc, 0, 0, 0);
+        if ((s & 3) == 3) side(8 + (s >> 2));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pend[r] = act_apply_fast(ACT, acc[r]);
+}
+
+// ptr = &out[point of this lane][4*h]; chunk g holds channels 8g + 4h .. +3
+__device__ __forceinline__ void c32_store_tile(const f32x16& pend, float* ptr, bool valid) {
+    if (valid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(f32x4*)(ptr + 8 * g) = f32x4{pend[4 * g], pend[4 * g + 1], pend[4 * g + 2], pend[4 * g + 3]};
+    }
+}
+
+template <int ACT>
 __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const float* __restrict__ X,
                                                                 const float* __restrict__ W0,
                                                                 const float* __restrict__ W1,
                                                                 const float* __restrict__ W2,
                                                                 float* __restrict__ out, int n_rows, int n_cols,
-                                                                int n_slabs, int act) {
+                                                                int n_slabs, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PIECE = 512;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;   // 8 LDS-DMA instructions per wave
+    const Smem sm = carve(smem, PIECE);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 31, h = lane >> 5, n = p & 3, rt = wave * 8 + (p >> 2);
-    // B operands: k-step s of segment g contracts channel 16*h + s
+    STAMP_DECL;
+    // weights: k-step s of segment g contracts channel 16*h + s ; W_g[(16h+s)][co = p]
     float Bw[3][16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -239,56 +453,134 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const
     }
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
+    SCN_SLAB_RANGE();
+    if (slab0 >= slab1) return;
+    f32x16 pend;                   // finished tile waiting to be stored (one slab late)
+    float* pend_ptr = nullptr;
+    bool pend_valid = false;
+    f32x4 zs[4], zl[4], zu[4];     // gathered tile
+    float* z_ptr = nullptr;
+    bool z_valid = false;
+    int cq[4];                     // lane-constant part of the swizzled chunk index
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cq[q] = (n * 8 + h * 4 + q) ^ (n >> 1);
+    const size_t slab_bytes = (size_t)n_cols * PIECE;
     for (; b < b_end; b += b_stride) {
-        __syncthreads();
+        wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
-        const int tw = P.tile_w[b * 4 + wave];
-        const int cbase = n * 8 + h * 4;
-        const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
+        __syncthreads();
+        const int tw = (dbg & 1) ? 0 : P.tile_w[b * BK_WAVES + wave];
+        const int rtc = rt < m.rows ? rt : m.rows - 1;
+        // per-lane source offsets of this wave's LDS-DMA instructions (the same for every slab of the block)
+        uint32_t goff[NDMA];
+        const int total = m.nsrc * CPP;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int c = (i * BK_WAVES + wave) * 64 + lane;
+            const int slot = c / CPP, pos = c % CPP;
+            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * PIECE + swz32(slot, pos) * 16 : 0u;
+        }
+        auto stage = [&](int slab, char* buf) {
+            const char* Xs = (const char*)X + (size_t)slab * slab_bytes;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int base = (i * BK_WAVES + wave) * 64;
+                if (base + lane < total)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xs + goff[i]),
+                                                     (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+            }
+        };
+        stage(slab0, sm.buf(0));
         for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 32>((const char*)X + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            __syncthreads();
-            f32x4 zs[4], zl[4], zu[4];
+            const char* cur = sm.buf((slab - slab0) & 1);
+            STAMP_START();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP_ADD(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP_ADD(1);
+            STAMP_ADD(2);
+            STAMP_ADD(3);
+            auto do_mfma = [&](int) {
+                // the previous tile's four 16-byte stores and the eight LDS-DMA loads of the next slab ride inside the chain
+                const f32x16 prev = pend;
+                float* const prev_ptr = pend_ptr;
+                const bool prev_valid = pend_valid && pend_ptr != nullptr;
+                const bool more = slab + 1 < slab1 && !(dbg & 4);
+                const char* Xn = (const char*)X + (size_t)(slab + 1) * slab_bytes;
+                char* nbuf = sm.buf((slab + 1 - slab0) & 1);
+                c32_mfma_epilogue<ACT>(zs, zl, zu, Bw, pend, [&](int k) {
+                    if (k < NDMA) {
+                        const int base = (k * BK_WAVES + wave) * 64;
+                        if (more && base + lane < total)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
+                                                             (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
+                    } else if (prev_valid && !(dbg & 8)) {
+                        const int g = k - NDMA;
+                        *(f32x4*)(prev_ptr + 8 * g) = f32x4{prev[4 * g], prev[4 * g + 1], prev[4 * g + 2], prev[4 * g + 3]};
+                    }
+                });
+                pend_ptr = z_ptr;
+                pend_valid = z_valid;
+            };
+            STAMP_ADD(5);
             {
-                const int slot = sm.self[rt];
-                const char* base = sm.stage + slot * PIECE;
+                const int slot = sm.self[rtc];
+                const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
+                const char* base = cur + slot * PIECE;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    zs[q] = *(const f32x4*)(base + swz32(slot, cbase + q) * 16);
+                    zs[q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
                     zl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                     zu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            }
-            for (int t = 0; t < tw; ++t) {
-                const int e = t * BK_R + rt;
-                const int slot = sm.slot[e];
-                const float a0 = sm.v0[e], a1 = sm.v1[e];
-                const char* base = sm.stage + slot * PIECE;
+                // one-entry look-ahead: the reads of entry k+1 are in flight while entry k is accumulated
+                const int rb = rtc * m.w;
+                f32x4 d[4];
+                EllPair e = ell_load(sm, rb);
+                if (tw > 0) {
+                    const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
+                    const char* b0 = cur + e.s0 * PIECE;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 d = *(const f32x4*)(base + swz32(slot, cbase + q) * 16);
-                    zl[q] += a0 * d;
-                    zu[q] += a1 * d;
+                    for (int q = 0; q < 4; ++q) d[q] = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+                }
+                for (int t = 0; t < tw; t += 2) {
+                    f32x4 d1[4];
+                    {
+                        const int x1 = (((e.s1 >> 1) & 1) << 2) | ((e.s1 & 1) << 1);
+                        const char* b1 = cur + e.s1 * PIECE;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d1[q] = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
+                    }
+                    const f32x4 v = e.v;
+                    if (t + 2 < tw) e = ell_load(sm, rb + t + 2);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        zl[q] += v[0] * d[q];
+                        zu[q] += v[1] * d[q];
+                    }
+                    if (t + 2 < tw) {
+                        const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
+                        const char* b0 = cur + e.s0 * PIECE;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) d[q] = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        zl[q] += v[2] * d1[q];
+                        zu[q] += v[3] * d1[q];
+                    }
                 }
             }
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zs[s >> 2][s & 3], Bw[0][s], acc, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zl[s >> 2][s & 3], Bw[1][s], acc, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zu[s >> 2][s & 3], Bw[2][s], acc, 0, 0, 0);
-            // D layout: column = lane&31 (output channel), row = (r&3) + 8*(r>>2) + 4*h (point)
-            float* o = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * 32) + p;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pt = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int prow = wave * 8 + (pt >> 2);
-                if (prow < m.rows) o[(prow * BK_NS + (pt & 3)) * 32] = act_apply(act, acc[r]);
-            }
+            z_ptr = out + (((size_t)slab * n_rows + m.row0 + rt) * BK_NS + n) * 32 + 4 * h;
+            z_valid = rt < m.rows;
+            STAMP_ADD(4);
+            do_mfma(slab);
+            STAMP_ADD(5);
         }
     }
+    STAMP_FLUSH();
+    if (pend_ptr) c32_store_tile(pend, pend_ptr, pend_valid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,7 +595,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
                                                                 int n_slabs, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 256;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
+    const Smem sm = carve(smem, PIECE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 15, g = lane >> 4, n = p & 3;
     const int rtA = wave * 8 + (p >> 2), rtB = rtA + 4;
@@ -316,31 +608,53 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
     }
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
+    SCN_SLAB_RANGE();
+    if (slab0 >= slab1) return;
+    const int chunk = n * 4 + g;
+    // D layout: column = lane&15 (channel), row = 4*g + r (point): row-in-quad = g, trajectory = r
+    const int prA = wave * 8 + g, prB = prA + 4;
+    f32x4 pendA, pendB;
+    float* pend_ptr = nullptr;
+    int pend_rows = 0;
     for (; b < b_end; b += b_stride) {
-        __syncthreads();
+        wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
-        const int tw = P.tile_w[b * 4 + wave];
-        const int chunk = n * 4 + g;
-        const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
+        __syncthreads();
+        const int tw = P.tile_w[b * BK_WAVES + wave];
+        const int rA = rtA < m.rows ? rtA : m.rows - 1, rB = rtB < m.rows ? rtB : m.rows - 1;
+        dma_stage<PIECE, 16>((const char*)X + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
         for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 16>((const char*)X + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            __syncthreads();
+            const char* cur = sm.buf((slab - slab0) & 1);
+            wait_vm_and_barrier();
+            if (slab + 1 < slab1)
+                dma_stage<PIECE, 16>((const char*)X + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                                     m.nsrc);
+            if (pend_ptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (prA < pend_rows) pend_ptr[(prA * BK_NS + r) * 16] = pendA[r];
+                    if (prB < pend_rows) pend_ptr[(prB * BK_NS + r) * 16] = pendB[r];
+                }
+            }
             f32x4 zsA, zsB, zlA = {0.f, 0.f, 0.f, 0.f}, zuA = zlA, zlB = zlA, zuB = zlA;
             {
-                const int sA = sm.self[rtA], sB = sm.self[rtB];
-                zsA = *(const f32x4*)(sm.stage + sA * PIECE + swz16(sA, chunk) * 16);
-                zsB = *(const f32x4*)(sm.stage + sB * PIECE + swz16(sB, chunk) * 16);
+                const int sA = sm.self[rA], sB = sm.self[rB];
+                zsA = *(const f32x4*)(cur + sA * PIECE + swz16(sA, chunk) * 16);
+                zsB = *(const f32x4*)(cur + sB * PIECE + swz16(sB, chunk) * 16);
             }
-            for (int t = 0; t < tw; ++t) {
-                const int eA = t * BK_R + rtA, eB = eA + 4;
-                const int sA = sm.slot[eA], sB = sm.slot[eB];
-                const f32x4 dA = *(const f32x4*)(sm.stage + sA * PIECE + swz16(sA, chunk) * 16);
-                const f32x4 dB = *(const f32x4*)(sm.stage + sB * PIECE + swz16(sB, chunk) * 16);
-                zlA += sm.v0[eA] * dA;
-                zuA += sm.v1[eA] * dA;
-                zlB += sm.v0[eB] * dB;
-                zuB += sm.v1[eB] * dB;
+            {
+                const int rbA = rA * m.w, rbB = rB * m.w;
+                EllPair nA = ell_load(sm, rbA), nB = ell_load(sm, rbB);
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair eA = nA, eB = nB;
+                    if (t + 2 < tw) { nA = ell_load(sm, rbA + t + 2); nB = ell_load(sm, rbB + t + 2); }
+                    const f32x4 dA0 = *(const f32x4*)(cur + eA.s0 * PIECE + swz16(eA.s0, chunk) * 16);
+                    const f32x4 dA1 = *(const f32x4*)(cur + eA.s1 * PIECE + swz16(eA.s1, chunk) * 16);
+                    const f32x4 dB0 = *(const f32x4*)(cur + eB.s0 * PIECE + swz16(eB.s0, chunk) * 16);
+                    const f32x4 dB1 = *(const f32x4*)(cur + eB.s1 * PIECE + swz16(eB.s1, chunk) * 16);
+                    zlA += eA.v[0] * dA0; zuA += eA.v[1] * dA0; zlA += eA.v[2] * dA1; zuA += eA.v[3] * dA1;
+                    zlB += eB.v[0] * dB0; zuB += eB.v[1] * dB0; zlB += eB.v[2] * dB1; zuB += eB.v[3] * dB1;
+                }
             }
             f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
 #pragma unroll
@@ -358,14 +672,20 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
                 accA = __builtin_amdgcn_mfma_f32_16x16x4f32(zuA[s], Bw[2][s], accA, 0, 0, 0);
                 accB = __builtin_amdgcn_mfma_f32_16x16x4f32(zuB[s], Bw[2][s], accB, 0, 0, 0);
             }
-            // D layout: column = lane&15 (output channel), row = 4*g + r (point): row-in-quad = g, trajectory = r
-            float* o = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * 16) + p;
-            const int prA = wave * 8 + g, prB = prA + 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (prA < m.rows) o[(prA * BK_NS + r) * 16] = act_apply(act, accA[r]);
-                if (prB < m.rows) o[(prB * BK_NS + r) * 16] = act_apply(act, accB[r]);
+                pendA[r] = act_apply_fast(act, accA[r]);
+                pendB[r] = act_apply_fast(act, accB[r]);
             }
+            pend_ptr = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * 16) + p;
+            pend_rows = m.rows;
+        }
+    }
+    if (pend_ptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (prA < pend_rows) pend_ptr[(prA * BK_NS + r) * 16] = pendA[r];
+            if (prB < pend_rows) pend_ptr[(prB * BK_NS + r) * 16] = pendB[r];
         }
     }
 }
@@ -383,91 +703,52 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
                                                                int n_slabs, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 16, CQ = C / 4;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
-    float* Z = (float*)(smem + smem_bytes(PIECE, P.ell_w_max));      // [BK_R*BK_NS][3]
+    const Smem sm = carve(smem, PIECE);
+    float* Z = (float*)(smem + smem_bytes(PIECE));                    // [2][BK_R*BK_NS][3]
     const int tid = threadIdx.x;
-    const int cq = tid % CQ;                                          // constant per thread: 256 % CQ == 0
-    f32x4 w0 = *(const f32x4*)(W0 + cq * 4), w1 = *(const f32x4*)(W1 + cq * 4), w2 = *(const f32x4*)(W2 + cq * 4);
+    const int cq = tid % CQ;                                          // constant per thread: 512 % CQ == 0
+    const f32x4 w0 = *(const f32x4*)(W0 + cq * 4), w1 = *(const f32x4*)(W1 + cq * 4), w2 = *(const f32x4*)(W2 + cq * 4);
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
-    const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
+    SCN_SLAB_RANGE();
+    if (slab0 >= slab1) return;
     for (; b < b_end; b += b_stride) {
-        __syncthreads();
+        wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
+        __syncthreads();
+        dma_stage<PIECE, 0>((const char*)X + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
         for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 0>((const char*)X + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            __syncthreads();
-            if (tid < BK_R * BK_NS) {
+            const float* st = (const float*)sm.buf((slab - slab0) & 1);
+            float* Zs = Z + ((slab - slab0) & 1) * (BK_R * BK_NS * 3);
+            wait_vm_and_barrier();
+            if (slab + 1 < slab1)
+                dma_stage<PIECE, 0>((const char*)X + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                                    m.nsrc);
+            if (tid < m.rows * BK_NS) {
                 const int rt = tid >> 2, n = tid & 3;
-                const float* st = (const float*)sm.stage;
                 float zs = st[sm.self[rt] * 4 + n], zl = 0.f, zu = 0.f;
-                const int tw = P.tile_w[b * 4 + (rt >> 3)];
-                for (int t = 0; t < tw; ++t) {
-                    const int e = t * BK_R + rt;
-                    const float d = st[sm.slot[e] * 4 + n];
-                    zl = fmaf(sm.v0[e], d, zl);
-                    zu = fmaf(sm.v1[e], d, zu);
+                const int tw = P.tile_w[b * BK_WAVES + (rt >> 3)];
+                const int rb = rt * m.w;
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair e = ell_load(sm, rb + t);
+                    const float d0 = st[e.s0 * 4 + n], d1 = st[e.s1 * 4 + n];
+                    zl = fmaf(e.v[0], d0, zl);
+                    zu = fmaf(e.v[1], d0, zu);
+                    zl = fmaf(e.v[2], d1, zl);
+                    zu = fmaf(e.v[3], d1, zu);
                 }
-                Z[tid * 3] = zs; Z[tid * 3 + 1] = zl; Z[tid * 3 + 2] = zu;
+                Zs[tid * 3] = zs; Zs[tid * 3 + 1] = zl; Zs[tid * 3 + 2] = zu;
             }
-            __syncthreads();
+            __syncthreads();   // Z visible (the DMA in flight is drained here too: acceptable for this light kernel)
             float* o = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * C);
             const int total = m.rows * BK_NS * CQ;
             for (int idx = tid; idx < total; idx += BK_THREADS) {
                 const int pt = idx / CQ;
-                const float zs = Z[pt * 3], zl = Z[pt * 3 + 1], zu = Z[pt * 3 + 2];
+                const float zs = Zs[pt * 3], zl = Zs[pt * 3 + 1], zu = Zs[pt * 3 + 2];
                 f32x4 v = zs * w0 + zl * w1 + zu * w2;
-                v[0] = act_apply(act, v[0]); v[1] = act_apply(act, v[1]);
-                v[2] = act_apply(act, v[2]); v[3] = act_apply(act, v[3]);
+                v[0] = act_apply_fast(act, v[0]); v[1] = act_apply_fast(act, v[1]);
+                v[2] = act_apply_fast(act, v[2]); v[3] = act_apply_fast(act, v[3]);
                 *(f32x4*)(o + (size_t)idx * 4) = v;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dual SpMM on K-float pieces (K % 4 == 0, K <= 128): ya = val0-operator * x, yb = val1-operator * x
-// ------------------------------------------------------------------------------------------------
-template <bool DUAL>
-__global__ __launch_bounds__(BK_THREADS, 2) void spmm_blocked_kernel(PlanDev P, const float* __restrict__ X,
-                                                                     float* __restrict__ ya, float* __restrict__ yb,
-                                                                     int n_rows, int n_cols, int n_slabs, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int piece = K * 4, cpp = K / 4;
-    const Smem sm = carve(smem, piece, P.ell_w_max);
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
-    for (; b < b_end; b += b_stride) {
-        __syncthreads();
-        const BlockMeta m = load_block(P, b, sm);
-        for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            {
-                const char* Xs = (const char*)X + (size_t)slab * n_cols * piece;
-                const int total = m.nsrc * cpp;
-                for (int c = threadIdx.x; c < total; c += BK_THREADS) {
-                    const int slot = c / cpp, ch = c - slot * cpp;
-                    *(f32x4*)(sm.stage + slot * piece + ch * 16) =
-                        *(const f32x4*)(Xs + (size_t)sm.srcrows[slot] * piece + ch * 16);
-                }
-            }
-            __syncthreads();
-            const size_t obase = ((size_t)slab * n_rows + m.row0) * K;
-            const int total = m.rows * cpp;
-            for (int idx = threadIdx.x; idx < total; idx += BK_THREADS) {
-                const int r = idx / cpp, ch = idx - r * cpp;
-                const int tw = P.tile_w[b * 4 + (r >> 3)];
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-                for (int t = 0; t < tw; ++t) {
-                    const int e = t * BK_R + r;
-                    const f32x4 d = *(const f32x4*)(sm.stage + sm.slot[e] * piece + ch * 16);
-                    a0 += sm.v0[e] * d;
-                    if (DUAL) a1 += sm.v1[e] * d;
-                }
-                *(f32x4*)(ya + obase + (size_t)idx * 4) = a0;
-                if (DUAL) *(f32x4*)(yb + obase + (size_t)idx * 4) = a1;
             }
         }
     }
@@ -476,12 +757,12 @@ __global__ __launch_bounds__(BK_THREADS, 2) void spmm_blocked_kernel(PlanDev P, 
 // ------------------------------------------------------------------------------------------------
 // backward, c_dz = c_aux = 32
 //   G = [dz | S_lower^T dz | S_upper^T dz] gathered like the forward; dx = (G @ [W0;W1;W2]^T) * act'(aux);
-//   dW_g += aux^T G_g via MFMA with the points on the contraction axis (G transposed through a per-wave LDS patch).
+//   dW_g += aux^T G_g via MFMA with the points on the contraction axis (G transposed through a per-wave LDS patch,
+//   16 points at a time).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 constexpr int T32_STRIDE = 36;    // floats per point row of the transpose patch (32 + 4 pad: 144 B)
@@ -495,10 +776,11 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
                                                                 float* __restrict__ partial, int n_rows, int n_cols,
                                                                 int n_slabs, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PIECE = 512;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* patch = (float*)(smem + smem_bytes(PIECE, P.ell_w_max)) + wave * (32 * T32_STRIDE);
+    constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
+    const Smem sm = carve(smem, PIECE);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* patch = (float*)(smem + smem_bytes(PIECE)) + wave * (16 * T32_STRIDE);
     const int p = lane & 31, h = lane >> 5, n = p & 3, rt = wave * 8 + (p >> 2);
     // dgrad B operands: k-step s of segment g contracts dz channel 16*h + s against W_g[ca = p][c]
     float Bt[3][16];
@@ -515,83 +797,138 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
         for (int r = 0; r < 16; ++r) dWacc[g][r] = 0.f;
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
-    const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
-    for (; b < b_end; b += b_stride) {
-        __syncthreads();
-        const BlockMeta m = load_block(P, b, sm);
-        const int tw = P.tile_w[b * 4 + wave];
-        const int cbase = n * 8 + h * 4;
-        for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 32>((const char*)DZ + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            // this lane's aux values: point pt(r) = (r&3) + 8*(r>>2) + 4*h, channel ca = p  (also the dW A operand)
-            const size_t tbase = ((size_t)slab * n_rows + m.row0) * (BK_NS * 32) + p;
-            float a[16];
+    SCN_SLAB_RANGE();
+    int cq[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pt = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int prow = wave * 8 + (pt >> 2);
-                a[r] = prow < m.rows ? aux[tbase + (prow * BK_NS + (pt & 3)) * 32] : 0.f;
-            }
-            __syncthreads();
+    for (int q = 0; q < 4; ++q) cq[q] = (n * 8 + h * 4 + q) ^ (n >> 1);
+    const size_t slab_bytes = (size_t)n_cols * PIECE;
+    if (slab0 < slab1)
+    for (; b < b_end; b += b_stride) {
+        wait_all_and_barrier();
+        const BlockMeta m = load_block(P, b, sm);
+        __syncthreads();
+        const int tw = P.tile_w[b * BK_WAVES + wave];
+        const int rtc = rt < m.rows ? rt : m.rows - 1;
+        uint32_t goff[NDMA];                          // per-lane LDS-DMA source offsets, constant over the block's slabs
+        const int total = m.nsrc * CPP;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int c = (i * BK_WAVES + wave) * 64 + lane;
+            const int slot = c / CPP, pos = c % CPP;
+            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * PIECE + swz32(slot, pos) * 16 : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int base = (i * BK_WAVES + wave) * 64;
+            if (base + lane < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)DZ + (size_t)slab0 * slab_bytes + goff[i]),
+                                                 (__attribute__((address_space(3))) void*)(sm.buf(0) + base * 16), 16, 0, 0);
+        }
+        const int rows_left = m.rows - wave * 8;      // rows of this wave's tile that exist (<= 0: none)
+        for (int slab = slab0; slab < slab1; ++slab) {
+            const char* cur = sm.buf((slab - slab0) & 1);
+            // aux / dx address of point pt(r) = (r&3) + 8*(r>>2) + 4*h, channel ca = p : tbase + pt*32
+            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * 32;   // wave-uniform tile base
+            const float* ap = aux + (rows_left > 0 ? tuni : 0);   // waves without rows read (and discard) element 0
+            float* dp = dx ? dx + tuni : nullptr;
+            const int L0 = p + 128 * h;                       // lane part of the element offset: pt*32 + p
+            wait_vm_and_barrier();
             f32x4 gs[4], gl[4], gu[4];
             {
-                const int slot = sm.self[rt];
-                const char* base = sm.stage + slot * PIECE;
+                const int slot = sm.self[rtc];
+                const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
+                const char* base = cur + slot * PIECE;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    gs[q] = *(const f32x4*)(base + swz32(slot, cbase + q) * 16);
+                    gs[q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
                     gl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                     gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            }
-            for (int t = 0; t < tw; ++t) {
-                const int e = t * BK_R + rt;
-                const int slot = sm.slot[e];
-                const float a0 = sm.v0[e], a1 = sm.v1[e];
-                const char* base = sm.stage + slot * PIECE;
+                const int rb = rtc * m.w;
+                EllPair en = ell_load(sm, rb);
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair e = en;
+                    if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
+                    const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
+                    const int x1 = (((e.s1 >> 1) & 1) << 2) | ((e.s1 & 1) << 1);
+                    const char* b0 = cur + e.s0 * PIECE;
+                    const char* b1 = cur + e.s1 * PIECE;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 d = *(const f32x4*)(base + swz32(slot, cbase + q) * 16);
-                    gl[q] += a0 * d;
-                    gu[q] += a1 * d;
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 d0 = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+                        gl[q] += e.v[0] * d0;
+                        gu[q] += e.v[1] * d0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 d1 = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
+                        gl[q] += e.v[2] * d1;
+                        gu[q] += e.v[3] * d1;
+                    }
                 }
             }
-            if (dx) {
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // dgrad chain: dH[point][ca] = sum_k G[point][k] * W[ca][k]   (D: column = lane&31 = ca, rows = points).
+            // Vector-memory issue rides inside the chain (the wave sits on the accumulator dependency anyway):
+            // first the LDS-DMA of the next slab, then this tile's 16 aux values (used right after the chain).
+            float a[16];
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool more = slab + 1 < slab1;
+            const char* Xn = (const char*)DZ + (size_t)(slab + 1) * slab_bytes;
+            char* nbuf = sm.buf((slab + 1 - slab0) & 1);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[s >> 2][s & 3], Bt[0][s], acc, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gl[s >> 2][s & 3], Bt[1][s], acc, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gu[s >> 2][s & 3], Bt[2][s], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pt = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int prow = wave * 8 + (pt >> 2);
-                    if (prow < m.rows)
-                        dx[tbase + (prow * BK_NS + (pt & 3)) * 32] = acc[r] * act_grad_from_output(act, a[r]);
+            for (int s = 0; s < 48; ++s) {
+                const int g = s >> 4, ss = s & 15;
+                const f32x4* G = g == 0 ? gs : (g == 1 ? gl : gu);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(G[ss >> 2][ss & 3], Bt[g][ss], acc, 0, 0, 0);
+                if ((s & 1) == 1) {
+                    const int k = s >> 1;                         // 24 side slots
+                    if (k < NDMA) {
+                        const int base = (k * BK_WAVES + wave) * 64;
+                        if (more && base + lane < total)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
+                                                             (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
+                    } else {
+                        const int r = k - NDMA;
+                        const bool ok = 2 * (r >> 2) + h < rows_left;          // row-in-tile of point pt(r,h) exists
+                        const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * 32 : 0];
+                        a[r] = ok ? v : 0.f;
+                    }
                 }
             }
-            // dW_g += aux^T G_g : A[i = ca][k = point] = a[s], B[k = point][j = c] = G_g[pt(s,h)][c = p]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(act, a[r]);
+            // dW_g += aux^T G_g : A[i = ca][k = point] = a[s], B[k = point][j = c] = G_g[pt(s,h)][c = p].
+            // Points 0..15 are k-steps s = 0..7, points 16..31 are s = 8..15; the patch holds 16 points at a time.
+            // The 16 dx stores ride inside these chains.
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const f32x4* src = g == 0 ? gs : (g == 1 ? gl : gu);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *(f32x4*)(patch + p * T32_STRIDE + 16 * h + 4 * q) = src[q];
-                wave_lds_fence();
+                for (int half = 0; half < 2; ++half) {
+                    if ((p >> 4) == half) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int pt = (s & 3) + 8 * (s >> 2) + 4 * h;
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], patch[pt * T32_STRIDE + p], dWacc[g], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) *(f32x4*)(patch + (p & 15) * T32_STRIDE + 16 * h + 4 * q) = src[q];
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int s = half * 8 + s8;
+                        const int pt16 = (s8 & 3) + 8 * (s8 >> 2) + 4 * h;      // point index within this half (0..15)
+                        dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], patch[pt16 * T32_STRIDE + p], dWacc[g], 0, 0, 0);
+                        const int k = (g * 2 + half) * 8 + s8;                   // 48 MFMAs, a store after every third
+                        if (dp && (k % 3) == 2) {
+                            const int r = k / 3;
+                            if (2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+                        }
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_fence();
             }
         }
     }
-    // reduce the four waves' dW tiles in a fixed order and emit this workgroup's partial [ca][slot*32 + c]
-    __syncthreads();
-    float* red = (float*)sm.stage;                              // 4 waves * 3 * 1024 floats = 48 KB
+    // reduce the eight waves' dW tiles in a fixed order and emit this workgroup's partial [ca][slot*32 + c]
+    wait_all_and_barrier();
+    float* red = (float*)sm.buf(0);                             // 8 waves * 3072 floats = 96 KB (both stage buffers)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -600,9 +937,13 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
             red[wave * 3072 + ca * 96 + g * 32 + p] = dWacc[g][r];
         }
     __syncthreads();
-    float* out = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
-    for (int i = threadIdx.x; i < 3072; i += BK_THREADS)
-        out[i] = (red[i] + red[3072 + i]) + (red[2 * 3072 + i] + red[3 * 3072 + i]);
+    float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
+    for (int i = threadIdx.x; i < 3072; i += BK_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) s += red[w * 3072 + i];
+        outp[i] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,9 +958,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
                                                                 int n_slabs, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 256;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
+    const Smem sm = carve(smem, PIECE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* patch = (float*)(smem + smem_bytes(PIECE, P.ell_w_max)) + wave * (2 * 16 * T16_STRIDE);
+    float* patch = (float*)(smem + smem_bytes(PIECE)) + wave * (2 * 16 * T16_STRIDE);
     const int p = lane & 15, g4 = lane >> 4, n = p & 3;
     const int rtA = wave * 8 + (p >> 2), rtB = rtA + 4;
     float Bt[3][4];
@@ -634,40 +975,63 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
     for (int g = 0; g < 3; ++g) dWacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
-    const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
+    SCN_SLAB_RANGE();
+    const int chunk = n * 4 + g4;
+    const int prA = wave * 8 + g4, prB = prA + 4;       // D-layout rows: point 4*g4 + r -> row-in-quad g4, trajectory r
+    if (slab0 < slab1)
     for (; b < b_end; b += b_stride) {
-        __syncthreads();
+        wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
-        const int tw = P.tile_w[b * 4 + wave];
-        const int chunk = n * 4 + g4;
-        const int prA = wave * 8 + g4, prB = prA + 4;       // D-layout rows: point 4*g4 + r -> row-in-quad g4, trajectory r
-        for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 16>((const char*)DZ + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            const size_t tbase = ((size_t)slab * n_rows + m.row0) * (BK_NS * 16) + p;
-            float aA[4], aB[4];
+        __syncthreads();
+        const int tw = P.tile_w[b * BK_WAVES + wave];
+        const int rA = rtA < m.rows ? rtA : m.rows - 1, rB = rtB < m.rows ? rtB : m.rows - 1;
+        dma_stage<PIECE, 16>((const char*)DZ + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        float nA[4], nB[4];                                  // aux of the next slab (fetched one slab ahead)
+        {
+            const size_t tb = ((size_t)slab0 * n_rows + m.row0) * (BK_NS * 16) + p;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                aA[r] = prA < m.rows ? aux[tbase + (prA * BK_NS + r) * 16] : 0.f;
-                aB[r] = prB < m.rows ? aux[tbase + (prB * BK_NS + r) * 16] : 0.f;
+                nA[r] = prA < m.rows ? aux[tb + (prA * BK_NS + r) * 16] : 0.f;
+                nB[r] = prB < m.rows ? aux[tb + (prB * BK_NS + r) * 16] : 0.f;
             }
-            __syncthreads();
+        }
+        for (int slab = slab0; slab < slab1; ++slab) {
+            const char* cur = sm.buf((slab - slab0) & 1);
+            const size_t tbase = ((size_t)slab * n_rows + m.row0) * (BK_NS * 16) + p;
+            wait_vm_and_barrier();
+            float aA[4], aB[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { aA[r] = nA[r]; aB[r] = nB[r]; }
+            if (slab + 1 < slab1) {
+                const size_t tb = tbase + (size_t)n_rows * (BK_NS * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    nA[r] = prA < m.rows ? aux[tb + (prA * BK_NS + r) * 16] : 0.f;
+                    nB[r] = prB < m.rows ? aux[tb + (prB * BK_NS + r) * 16] : 0.f;
+                }
+                dma_stage<PIECE, 16>((const char*)DZ + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                                     m.nsrc);
+            }
             f32x4 G[3][2];
             {
-                const int sA = sm.self[rtA], sB = sm.self[rtB];
-                G[0][0] = *(const f32x4*)(sm.stage + sA * PIECE + swz16(sA, chunk) * 16);
-                G[0][1] = *(const f32x4*)(sm.stage + sB * PIECE + swz16(sB, chunk) * 16);
+                const int sA = sm.self[rA], sB = sm.self[rB];
+                G[0][0] = *(const f32x4*)(cur + sA * PIECE + swz16(sA, chunk) * 16);
+                G[0][1] = *(const f32x4*)(cur + sB * PIECE + swz16(sB, chunk) * 16);
                 G[1][0] = G[1][1] = G[2][0] = G[2][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            for (int t = 0; t < tw; ++t) {
-                const int eA = t * BK_R + rtA, eB = eA + 4;
-                const int sA = sm.slot[eA], sB = sm.slot[eB];
-                const f32x4 dA = *(const f32x4*)(sm.stage + sA * PIECE + swz16(sA, chunk) * 16);
-                const f32x4 dB = *(const f32x4*)(sm.stage + sB * PIECE + swz16(sB, chunk) * 16);
-                G[1][0] += sm.v0[eA] * dA;
-                G[2][0] += sm.v1[eA] * dA;
-                G[1][1] += sm.v0[eB] * dB;
-                G[2][1] += sm.v1[eB] * dB;
+            {
+                const int rbA = rA * m.w, rbB = rB * m.w;
+                EllPair nA = ell_load(sm, rbA), nB = ell_load(sm, rbB);
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair eA = nA, eB = nB;
+                    if (t + 2 < tw) { nA = ell_load(sm, rbA + t + 2); nB = ell_load(sm, rbB + t + 2); }
+                    const f32x4 dA0 = *(const f32x4*)(cur + eA.s0 * PIECE + swz16(eA.s0, chunk) * 16);
+                    const f32x4 dA1 = *(const f32x4*)(cur + eA.s1 * PIECE + swz16(eA.s1, chunk) * 16);
+                    const f32x4 dB0 = *(const f32x4*)(cur + eB.s0 * PIECE + swz16(eB.s0, chunk) * 16);
+                    const f32x4 dB1 = *(const f32x4*)(cur + eB.s1 * PIECE + swz16(eB.s1, chunk) * 16);
+                    G[1][0] += eA.v[0] * dA0; G[2][0] += eA.v[1] * dA0; G[1][0] += eA.v[2] * dA1; G[2][0] += eA.v[3] * dA1;
+                    G[1][1] += eB.v[0] * dB0; G[2][1] += eB.v[1] * dB0; G[1][1] += eB.v[2] * dB1; G[2][1] += eB.v[3] * dB1;
+                }
             }
             if (dx) {
                 f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
@@ -688,27 +1052,31 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
             for (int g = 0; g < 3; ++g) {
                 *(f32x4*)(patch + p * T16_STRIDE + 4 * g4) = G[g][0];
                 *(f32x4*)(patch + 16 * T16_STRIDE + p * T16_STRIDE + 4 * g4) = G[g][1];
-                wave_lds_fence();
+                wave_lds_sync();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int pt = 4 * g4 + s;
                     dWacc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[s], patch[pt * T16_STRIDE + p], dWacc[g], 0, 0, 0);
                     dWacc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[s], patch[16 * T16_STRIDE + pt * T16_STRIDE + p], dWacc[g], 0, 0, 0);
                 }
-                wave_lds_fence();
+                wave_lds_sync();
             }
         }
     }
-    __syncthreads();
-    float* red = (float*)sm.stage;                              // 4 waves * 768 floats
+    wait_all_and_barrier();
+    float* red = (float*)sm.buf(0);                             // 8 waves * 768 floats
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave * 768 + (4 * g4 + r) * 48 + g * 16 + p] = dWacc[g][r];
     __syncthreads();
-    float* out = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 768;
-    for (int i = threadIdx.x; i < 768; i += BK_THREADS)
-        out[i] = (red[i] + red[768 + i]) + (red[2 * 768 + i] + red[3 * 768 + i]);
+    float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 768;
+    for (int i = threadIdx.x; i < 768; i += BK_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) s += red[w * 768 + i];
+        outp[i] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -722,43 +1090,75 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c1_kernel(PlanDev P, const 
                                                                int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = BK_NS * C * 4, CPP = PIECE / 16, CQ = C / 4;
-    const Smem sm = carve(smem, PIECE, P.ell_w_max);
+    const Smem sm = carve(smem, PIECE);
     const int tid = threadIdx.x;
     f32x4 acc[3];
     acc[0] = acc[1] = acc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
-    const int slab0 = blockIdx.y * n_slabs / gridDim.y, slab1 = (blockIdx.y + 1) * n_slabs / gridDim.y;
+    SCN_SLAB_RANGE();
+    if (slab0 < slab1)
     for (; b < b_end; b += b_stride) {
-        __syncthreads();
+        wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
+        __syncthreads();
+        dma_stage<PIECE, 0>((const char*)DZ + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        const int total = m.rows * CPP;                           // (row, chunk) pairs; chunk = n*CQ + cq
+        float xn[4];                                              // x of the next slab (fetched one slab ahead)
+        {
+            const float* xs = aux + ((size_t)slab0 * n_rows + m.row0) * BK_NS;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = tid + k * BK_THREADS;
+                xn[k] = idx < total ? xs[(idx / CPP) * BK_NS + (idx % CPP) / CQ] : 0.f;
+            }
+        }
         for (int slab = slab0; slab < slab1; ++slab) {
-            __syncthreads();
-            stage_pieces<PIECE, 0>((const char*)DZ + (size_t)slab * n_cols * PIECE, sm, m.nsrc);
-            __syncthreads();
-            const float* xs = aux + ((size_t)slab * n_rows + m.row0) * BK_NS;
-            const int total = m.rows * CPP;                       // (row, chunk) pairs; chunk = n*CQ + cq
-            for (int idx = tid; idx < total; idx += BK_THREADS) {  // 256 % CPP == 0 -> cq constant per thread
-                const int r = idx / CPP, ch = idx - r * CPP;
-                const float x = xs[r * BK_NS + ch / CQ];
-                const int tw = P.tile_w[b * 4 + (r >> 3)];
-                f32x4 gl = {0.f, 0.f, 0.f, 0.f}, gu = gl;
-                const f32x4 gsv = *(const f32x4*)(sm.stage + sm.self[r] * PIECE + ch * 16);
-                for (int t = 0; t < tw; ++t) {
-                    const int e = t * BK_R + r;
-                    const f32x4 d = *(const f32x4*)(sm.stage + sm.slot[e] * PIECE + ch * 16);
-                    gl += sm.v0[e] * d;
-                    gu += sm.v1[e] * d;
+            const char* cur = sm.buf((slab - slab0) & 1);
+            wait_vm_and_barrier();
+            float xv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[k] = xn[k];
+            if (slab + 1 < slab1) {
+                const float* xs = aux + ((size_t)(slab + 1) * n_rows + m.row0) * BK_NS;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = tid + k * BK_THREADS;
+                    xn[k] = idx < total ? xs[(idx / CPP) * BK_NS + (idx % CPP) / CQ] : 0.f;
                 }
-                acc[0] += x * gsv;
-                acc[1] += x * gl;
-                acc[2] += x * gu;
+                dma_stage<PIECE, 0>((const char*)DZ + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                                    m.nsrc);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                         // BK_R * CPP <= 4 * BK_THREADS
+                const int idx = tid + k * BK_THREADS;
+                if (idx < total) {
+                    const int r = idx / CPP, ch = idx - r * CPP;
+                    const int tw = P.tile_w[b * BK_WAVES + (r >> 3)];
+                    f32x4 gl = {0.f, 0.f, 0.f, 0.f}, gu = gl;
+                    const f32x4 gsv = *(const f32x4*)(cur + sm.self[r] * PIECE + ch * 16);
+                    const int rb = r * m.w;
+                    EllPair en = ell_load(sm, rb);
+                    for (int t = 0; t < tw; t += 2) {
+                        const EllPair e = en;
+                        if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
+                        const f32x4 d0 = *(const f32x4*)(cur + e.s0 * PIECE + ch * 16);
+                        const f32x4 d1 = *(const f32x4*)(cur + e.s1 * PIECE + ch * 16);
+                        gl += e.v[0] * d0;
+                        gu += e.v[1] * d0;
+                        gl += e.v[2] * d1;
+                        gu += e.v[3] * d1;
+                    }
+                    acc[0] += xv[k] * gsv;
+                    acc[1] += xv[k] * gl;
+                    acc[2] += xv[k] * gu;
+                }
             }
         }
     }
     // threads with equal cq = tid % CQ hold the same channels: reduce over them in a fixed order
-    __syncthreads();
-    f32x4* red = (f32x4*)sm.stage;                                // [3][256]
+    wait_all_and_barrier();
+    f32x4* red = (f32x4*)sm.buf(0);                               // [3][BK_THREADS]
 #pragma unroll
     for (int g = 0; g < 3; ++g) red[g * BK_THREADS + tid] = acc[g];
     __syncthreads();
@@ -766,12 +1166,12 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c1_kernel(PlanDev P, const 
         const int g = tid / CQ, cq = tid - g * CQ;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int t = cq; t < BK_THREADS; t += CQ) s += red[g * BK_THREADS + t];
-        float* out = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (3 * C) + g * C + cq * 4;
-        out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; out[3] = s[3];
+        float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (3 * C) + g * C + cq * 4;
+        outp[0] = s[0]; outp[1] = s[1]; outp[2] = s[2]; outp[3] = s[3];
     }
 }
 
-// dW_slot[i] += sum over partials (fixed order).  layout: partial[b][ca*ncols3 + slot*c + cc]
+// dW_slot[i] += sum over partials (fixed order).  layout: partial[b][ca*3c + slot*c + cc]
 __global__ void blocked_dw_reduce(const float* __restrict__ partial, int n_partials, int c_aux, int c,
                                   float* __restrict__ dW0, float* __restrict__ dW1, float* __restrict__ dW2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -800,12 +1200,15 @@ static bool scone_shape(const scn_conv_s* c) {
     return c->plan.built && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 2;
 }
 
-static void launch_grid(const scn_conv_s* c, int n_slabs, dim3& grid) {
+// persistent grid: workgroups per CU by LDS footprint, blocks strided XCD-contiguously; small operators split slabs
+static void launch_grid(const scn_conv_s* c, int n_slabs, size_t lds, dim3& grid) {
     const int nb = c->plan.dev.n_blocks;
-    int gx = std::min(512, ((nb + 7) / 8) * 8);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int cap = 256 * per_cu;
+    int gx = std::min(cap, ((nb + 7) / 8) * 8);
     gx = std::max(gx, 8);
     int gy = 1;
-    if (gx < 512) gy = std::max(1, std::min(n_slabs, 512 / gx));
+    if (gx < cap) gy = std::max(1, std::min(n_slabs, cap / gx));
     grid = dim3(gx, gy);
 }
 
@@ -819,25 +1222,41 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
                     const float* const* W, int c_out, int act, float* out, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
     dim3 grid;
-    launch_grid(c, n_slabs, grid);
     const int ci = c_in[0];
     const int nr = c->n_rows, nc = c->g[0].n_cols;
     if (ci == 32) {
-        const size_t lds = smem_bytes(512, P.ell_w_max);
-        SCN_ENSURE_LDS(fwd_c32_kernel, lds);
-        hipLaunchKernelGGL(fwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
-                           n_slabs, act);
+        const char* dbg_env = getenv("SCN_DBG");
+        const int dbg = dbg_env ? atoi(dbg_env) : 0;
+        const size_t lds = smem_bytes(512);
+        SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_NONE>, lds);
+        SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_TANH>, lds);
+        SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_RELU>, lds);
+        SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_LEAKY_RELU>, lds);
+        launch_grid(c, n_slabs, lds, grid);
+#define SCN_LAUNCH_FWD32(A)                                                                                       \
+    hipLaunchKernelGGL(fwd_c32_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc, \
+                       n_slabs, dbg)
+        switch (act) {
+            case SCN_ACT_TANH: SCN_LAUNCH_FWD32(SCN_ACT_TANH); break;
+            case SCN_ACT_RELU: SCN_LAUNCH_FWD32(SCN_ACT_RELU); break;
+            case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_FWD32(SCN_ACT_LEAKY_RELU); break;
+            default: SCN_LAUNCH_FWD32(SCN_ACT_NONE); break;
+        }
     } else if (ci == 16) {
-        const size_t lds = smem_bytes(256, P.ell_w_max);
+        const size_t lds = smem_bytes(256);
         SCN_ENSURE_LDS(fwd_c16_kernel, lds);
+        launch_grid(c, n_slabs, lds, grid);
         hipLaunchKernelGGL(fwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
                            n_slabs, act);
-    } else if (c_out == 32) {
-        hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), smem_bytes(16, P.ell_w_max, BK_R * BK_NS * 12), st, P,
-                           src[0], W[0], W[1], W[2], out, nr, nc, n_slabs, act);
     } else {
-        hipLaunchKernelGGL(fwd_c1_kernel<16>, grid, dim3(BK_THREADS), smem_bytes(16, P.ell_w_max, BK_R * BK_NS * 12), st, P,
-                           src[0], W[0], W[1], W[2], out, nr, nc, n_slabs, act);
+        const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
+        launch_grid(c, n_slabs, lds, grid);
+        if (c_out == 32)
+            hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
+                               n_slabs, act);
+        else
+            hipLaunchKernelGGL(fwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
+                               n_slabs, act);
     }
     SCN_LAUNCH_CHECK();
     return SCN_OK;
@@ -850,11 +1269,17 @@ bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz
     return (cd == 16 || cd == 32) && c_aux == 1 && !has_dx;
 }
 
+static size_t bwd_lds(int cd, int c_aux) {
+    if (c_aux == 32) return smem_bytes(512, BK_WAVES * 16 * T32_STRIDE * 4);
+    if (c_aux == 16) return smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4);
+    return smem_bytes(BK_NS * cd * 4);
+}
+
 size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux) {
     if (!blocked_backward_supported(c, ns, c_dz, c_aux, false) && !blocked_backward_supported(c, ns, c_dz, c_aux, true))
         return 0;
     dim3 grid;
-    launch_grid(c, n_slabs, grid);
+    launch_grid(c, n_slabs, bwd_lds(c_dz[0], c_aux), grid);
     return (size_t)grid.x * grid.y * c_aux * 3 * c_dz[0] * sizeof(float);
 }
 
@@ -863,27 +1288,25 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
                      float* const* dW, void* ws, size_t ws_bytes, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
     dim3 grid;
-    launch_grid(c, n_slabs, grid);
     const int cd = c_dz[0];
     const int nr = c->n_rows, nc = c->g[0].n_cols;
     float* partial = (float*)ws;
+    const size_t lds = bwd_lds(cd, c_aux);
+    launch_grid(c, n_slabs, lds, grid);
     if (c_aux == 32) {
-        const size_t lds = smem_bytes(512, P.ell_w_max, 4 * 32 * T32_STRIDE * 4);
         SCN_ENSURE_LDS(bwd_c32_kernel, lds);
         hipLaunchKernelGGL(bwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
                            nc, n_slabs, act);
     } else if (c_aux == 16) {
-        const size_t lds = smem_bytes(256, P.ell_w_max, 4 * 2 * 16 * T16_STRIDE * 4);
         SCN_ENSURE_LDS(bwd_c16_kernel, lds);
         hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
                            nc, n_slabs, act);
     } else if (cd == 32) {
-        SCN_ENSURE_LDS(bwd_c1_kernel<32>, smem_bytes(512, P.ell_w_max));
-        hipLaunchKernelGGL(bwd_c1_kernel<32>, grid, dim3(BK_THREADS), smem_bytes(512, P.ell_w_max), st, P, dz[0], aux, partial,
-                           nr, nc, n_slabs);
+        SCN_ENSURE_LDS(bwd_c1_kernel<32>, lds);
+        hipLaunchKernelGGL(bwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
     } else {
-        hipLaunchKernelGGL(bwd_c1_kernel<16>, grid, dim3(BK_THREADS), smem_bytes(256, P.ell_w_max), st, P, dz[0], aux, partial,
-                           nr, nc, n_slabs);
+        SCN_ENSURE_LDS(bwd_c1_kernel<16>, lds);
+        hipLaunchKernelGGL(bwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
     }
     SCN_LAUNCH_CHECK();
     const int per = c_aux * 3 * cd;
@@ -900,18 +1323,26 @@ bool blocked_spmm_supported(const scn_conv_s* c, int k) {
 int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
     dim3 grid;
-    launch_grid(c, n_slabs, grid);
-    const size_t lds = smem_bytes(k * 4, P.ell_w_max);
+    const size_t lds = smem_bytes(k * 4, 16);
+    launch_grid(c, n_slabs, lds, grid);
     SCN_ENSURE_LDS(spmm_blocked_kernel<true>, lds);
     SCN_ENSURE_LDS(spmm_blocked_kernel<false>, lds);
     if (yb)
-        hipLaunchKernelGGL(spmm_blocked_kernel<true>, grid, dim3(BK_THREADS), lds, st, P, x, ya, yb, c->n_rows, c->g[0].n_cols,
+        hipLaunchKernelGGL(spmm_blocked_kernel<true>, grid, dim3(SP_THREADS), lds, st, P, x, ya, yb, c->n_rows, c->g[0].n_cols,
                            n_slabs, k);
     else
-        hipLaunchKernelGGL(spmm_blocked_kernel<false>, grid, dim3(BK_THREADS), lds, st, P, x, ya, yb, c->n_rows,
+        hipLaunchKernelGGL(spmm_blocked_kernel<false>, grid, dim3(SP_THREADS), lds, st, P, x, ya, yb, c->n_rows,
                            c->g[0].n_cols, n_slabs, k);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
 
 }  // namespace scn
+
+#ifdef SCN_STAMPS
+extern "C" int scn_debug_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(scn::g_stamps), 64) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(scn::g_stamps), z, 64) != hipSuccess) return -3; }
+    return 0;
+}
+#endif

@@ -30,6 +30,22 @@ void set_hip_error(hipError_t e, const char* where);
     } while (0)
 
 // activation and its derivative expressed through the OUTPUT value y (what the backward has at hand)
+// tanh to ~3e-7 absolute: odd Taylor polynomial below 1/8, 1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32 above
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
+    const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+    return ax < 0.125f ? poly : copysignf(r, x);
+}
+__device__ __forceinline__ float act_apply_fast(int act, float z) {
+    switch (act) {
+        case SCN_ACT_TANH: return fast_tanh(z);
+        case SCN_ACT_RELU: return fmaxf(z, 0.f);
+        case SCN_ACT_LEAKY_RELU: return z >= 0.f ? z : 0.01f * z;
+        default: return z;
+    }
+}
 __device__ __forceinline__ float act_apply(int act, float z) {
     switch (act) {
         case SCN_ACT_TANH: return tanhf(z);
@@ -62,11 +78,12 @@ struct Group {
 };
 
 // ---- LDS-blocked execution plan of a single-group operator (scn_blocked.hip) ----
-constexpr int BK_R = 32;        // output rows per block (upper bound; 8 per wave)
-constexpr int BK_SRC = 96;      // staged source pieces per block (upper bound)
+constexpr int BK_WAVES = 8;
+constexpr int BK_R = 8 * BK_WAVES;   // output rows per block (upper bound; 8 per wave)
+constexpr int BK_SRC = 128;     // staged source pieces per block (upper bound)
 constexpr int BK_NS = 4;        // trajectories per slab the blocked kernels are built for
-constexpr int BK_THREADS = 256;
-constexpr int BK_MAXW = 96;     // widest ELL row a block may carry
+constexpr int BK_THREADS = 64 * BK_WAVES;
+constexpr int BK_ELL_CAP = 1360;  // ELL entries (rows-in-block x padded width) a block may carry
 
 // device view passed to kernels by value
 struct PlanDev {
@@ -77,10 +94,9 @@ struct PlanDev {
     const int32_t* src_rows;    // staged source rows, ascending within a block
     const int32_t* ell_ptr;     // [n_blocks] entry offset (entries are [t][BK_R])
     const uint8_t* width;       // [n_blocks] padded entries per row
-    const uint8_t* tile_w;      // [n_blocks][4] entries needed by each wave's 8 rows
+    const uint8_t* tile_w;      // [n_blocks][BK_WAVES] entries needed by each wave's 8 rows
     const uint8_t* ell_slot;    // local slot of entry
-    const float* ell_v0;
-    const float* ell_v1;
+    const float2* ell_v;        // (val0, val1) of entry
     const uint8_t* self_slot;   // [n_blocks][BK_R] slot of the row itself (identity shift)
 };
 

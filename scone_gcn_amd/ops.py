@@ -447,14 +447,17 @@ def get_bunch_plan(shifts, nbrhoods, device):
 
 
 def micro_batch_size(n_rows_total, widths, n, ns=NS, budget_bytes=None, device=None):
-    """Trajectories per micro-batch so that saved activations + two gradient buffers fit the budget."""
+    """Trajectories per micro-batch so that saved activations + two gradient buffers fit the budget; the batch is
+    cut into equal micro-batches (multiples of ns)."""
     if budget_bytes is None:
         free, total = torch.cuda.mem_get_info(device)
         budget_bytes = 0.35 * total
     per_sample = 4.0 * n_rows_total * (sum(widths) + 2 * max(widths))
-    mb = int(budget_bytes // max(per_sample, 1.0))
-    mb = max(ns, min(mb, 16384) // ns * ns)
-    return min(mb, pad_count(n, ns))
+    mb_max = int(budget_bytes // max(per_sample, 1.0))
+    mb_max = max(ns, min(mb_max, 16384) // ns * ns)
+    n_pad = pad_count(n, ns)
+    n_chunks = -(-n_pad // mb_max)
+    return pad_count(-(-n_pad // n_chunks), ns)
 
 
 def as_device_weights(weights, device):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Run each hot kernel a few times on the |E|~1M complex (for rocprofv3 --kernel-trace / --pmc passes)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te   # noqa: E402
+from scone_gcn_amd.complex import SimplicialComplex                                      # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--edges", type=int, default=1_000_000)
+ap.add_argument("--hidden", type=int, default=32)
+ap.add_argument("--slabs", type=int, default=32)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--which", default="spmm,fwd,bwd,fwd1,bwd1")
+a = ap.parse_args()
+cx = g.random_SC_graph(g.calibrate_n_points(a.edges))
+sc = SimplicialComplex(cx)
+shifts, readout, _ = te.setup_from_complex(sc, "scone")
+plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+print("plan blocks, sources/row:", plan.conv.plan_info(), flush=True)
+E, C, S = cx.n_edges, a.hidden, a.slabs
+dev = "cuda"
+W = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
+W1 = [torch.randn(1, C, device=dev) * 0.1 for _ in range(3)]
+x = torch.randn(S, E, 4, C, device=dev)
+x1 = torch.randn(S, E, 4, 1, device=dev)
+which = a.which.split(",")
+with ops.KernelTimer() as kt:
+    for _ in range(a.reps):
+        if "spmm" in which:
+            plan.conv.spmm_dual(x.view(S, E, 4 * C))
+        if "fwd" in which:
+            plan.conv.forward([x], W, C, "tanh")
+        if "fwd1" in which:
+            plan.conv.forward([x1], W1, C, "tanh")
+        if "bwd" in which:
+            plan.conv.backward([x], W, x, "tanh", True, [torch.zeros_like(w) for w in W])
+        if "bwd1" in which:
+            plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
+for k, (n, ms) in kt.summary().items():
+    print(k, n, "%.3f ms" % ms, flush=True)

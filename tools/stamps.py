@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic: run fwd_c32 from the -DSCN_STAMPS build and print where a wave's cycles go per slab iteration."""
+import ctypes, os, sys, subprocess
+os.environ["SCN_LIB_PATH"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libscone_hip_stamps.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scone_gcn_amd import _lib, ops, synthetic_data_gen as g, trajectory_experiments as te
+from scone_gcn_amd.complex import SimplicialComplex
+lib = _lib.load()
+cx = g.random_SC_graph(g.calibrate_n_points(1_000_000)); sc = SimplicialComplex(cx)
+shifts, readout, _ = te.setup_from_complex(sc, "scone")
+plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+E, C, S = cx.n_edges, 32, 32
+W = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
+x = torch.randn(S, E, 4, C, device="cuda")
+plan.conv.forward([x], W, C, "tanh"); torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 8)()
+lib.scn_debug_stamps = ctypes.CDLL(os.environ["SCN_LIB_PATH"]).scn_debug_stamps
+lib.scn_debug_stamps(buf, 1)
+plan.conv.forward([x], W, C, "tanh"); torch.cuda.synchronize()
+lib.scn_debug_stamps(buf, 0)
+names = ["wait vmcnt(0)", "barrier", "dma issue", "stores", "gather", "mfma+epilogue"]
+waves = buf[7]; tot = sum(buf[i] for i in range(6))
+iters = 16505 * 32 * 8 / max(waves, 1)
+print("waves", waves, "slab iterations per wave %.0f" % iters)
+for i, n in enumerate(names):
+    print("%-14s %6.1f %%   %8.0f cycles per iteration" % (n, 100.0 * buf[i] / tot, buf[i] / waves / iters))
+print("total per iteration %.0f cycles (memtime ticks)" % (tot / waves / iters))
