@@ -331,6 +331,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
         }
         __syncthreads();
         const int total = m.rows * cpp;
+        const bool wave_uniform_rows = cpp >= 8 && (64 % cpp) == 0;
         dma_stage_sp((const char*)X + (size_t)slab0 * n_cols * piece, sm.buf(0), sm, m.nsrc, piece, cpp);
         for (int slab = slab0; slab < slab1; ++slab) {
             const int cur_off = ((slab - slab0) & 1) * sm.buf_stride;
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
                 if (idx < total) {
                     const int r = idx / cpp, ch = idx - r * cpp;
-                    const int tw = __builtin_amdgcn_readfirstlane(tws[r >> 3]);   // a wave's lanes share the row group
+                    int tw = tws[r >> 3];
+                    if (wave_uniform_rows) tw = __builtin_amdgcn_readfirstlane(tw);   // the wave's lanes share one row group
                     const int rb = r * m.w;
                     const char* cbase = sm.buf0 + cur_off + ch * 16;
 #pragma unroll 2
