@@ -1,0 +1,75 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol include/*.h declares.
+No compute call is made here (that is the -m gpu suite)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "scone_gcn_amd", "libscone_hip.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["bash", os.path.join(ROOT, "scone_gcn_amd", "csrc", "build.sh")])
+    return ctypes.CDLL(LIB)
+
+
+def _declared():
+    names = set()
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        if f.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", f)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(scn_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 16
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export " + n
+
+
+def test_python_binding_covers_the_header():
+    from scone_gcn_amd import _lib
+    assert set(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_strings(lib):
+    lib.scn_version.restype = ctypes.c_int
+    lib.scn_error_string.restype = ctypes.c_char_p
+    assert lib.scn_version() >= 100
+    assert lib.scn_error_string(0) == b"ok"
+    assert b"shape" in lib.scn_error_string(-2) and b"unsupported" in lib.scn_error_string(-4)
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu(lib):
+    h = ctypes.c_void_p()
+    assert lib.scn_conv_create(0, 1, None, ctypes.byref(h)) == -1      # SCN_ERR_BAD_ARG
+    assert lib.scn_conv_forward(None, 1, 4, None, None, None, 16, 1, None, None) == -1
+    assert lib.scn_adam_step(ctypes.c_int64(0), None, None, None, None, ctypes.c_float(1e-3), ctypes.c_float(.9),
+                             ctypes.c_float(.999), ctypes.c_float(1e-8), 0, ctypes.c_float(0), ctypes.c_float(1),
+                             None) == -2                                # SCN_ERR_BAD_SHAPE
+    assert lib.scn_conv_destroy(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from scone_gcn_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_model_functions_refuse_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scone_gcn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.default_device()

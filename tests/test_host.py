@@ -1,0 +1,170 @@
+"""CPU tests of the host side: sparse generator / operator builder against the golden fixtures and the dense oracle,
+layouts, flow containers, dataset folder IO, flag parser.  No GPU, no HIP calls."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import scone_oracle as so
+from scone_gcn_amd import synthetic_data_gen as g
+from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+from scone_gcn_amd.complex import Layout, SimplicialComplex, hilbert_index, union_pattern
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cx():
+    return g.random_SC_graph(400)
+
+
+def test_generator_reproduces_reference_complex_bit_for_bit(cx, cfg1):
+    assert cx.n_edges == 1001 and cx.n_faces == 649
+    assert np.array_equal(cx.edges, cfg1["edges"]) and np.array_equal(cx.faces, cfg1["faces"])
+    assert np.array_equal(cx.coords, cfg1["coords"])
+    B1, B2 = g.incidence_matrices(cx)
+    assert np.array_equal(B1.toarray(), cfg1["B1"]) and np.array_equal(B2.toarray(), cfg1["B2"])
+    e2, f2 = g.complex_from_incidence(cfg1["B1"], cfg1["B2"])
+    assert np.array_equal(e2, cx.edges) and np.array_equal(f2, cx.faces)
+
+
+def test_sparse_operators_equal_dense_oracle(cx, cfg1):
+    sc = SimplicialComplex(cx)
+    L_lo, L_up = so.scone_shifts(cfg1["B1"], cfg1["B2"])
+    s = sc.scone_shifts()
+    assert np.array_equal(s[0].toarray(), L_lo) and np.array_equal(s[1].toarray(), L_up)
+    e = sc.ebli_shifts()
+    E1, E2 = so.ebli_shifts(cfg1["B1"], cfg1["B2"])
+    assert np.array_equal(e[0].toarray(), E1) and np.array_equal(e[1].toarray(), E2)
+    flips = sc.flip_vector(1)
+    F = so.flip_matrix(cx.n_edges)
+    assert np.array_equal(np.diag(F), flips)
+    sf = sc.scone_shifts(flips)
+    Lf = so.scone_shifts(cfg1["B1"], cfg1["B2"], F)
+    assert np.array_equal(sf[0].toarray(), Lf[0]) and np.array_equal(sf[1].toarray(), Lf[1])
+    assert s[0].is_symmetric() and s[1].is_symmetric()
+
+
+def test_closed_form_bunch_shifts_match_reference(cx):
+    gold = np.load(os.path.join(GOLDEN, "cfg1_bunch.npz"))
+    B1, B2 = g.incidence_matrices(cx)
+    S = compute_shift_matrices(B1, B2)
+    for name, M in zip(["S_00", "S_10", "S_01", "S_11", "S_21", "S_12", "S_22"], S):
+        ref = so.dense_from_coo(gold[name + "_row"], gold[name + "_col"], gold[name + "_val"], gold[name + "_shape"])
+        assert sp.issparse(M) and np.abs(M.toarray() - ref).max() <= 1e-12, name
+    sc = SimplicialComplex(cx)
+    shifts = sc.bunch_shifts()
+    assert [s.shape for s in shifts] == [(400, 400), (400, 1001), (1001, 400), (1001, 1001), (1001, 649), (649, 1001), (649, 649)]
+    assert not shifts[3].is_symmetric()              # S_11 is not symmetric
+
+
+def test_layout_is_a_permutation_and_device_csr_is_conjugated(cx):
+    sc = SimplicialComplex(cx)
+    lay = sc.layout
+    for lvl in range(3):
+        assert np.array_equal(np.sort(lay.order[lvl]), np.arange(lay.sizes[lvl]))
+        assert np.array_equal(lay.perm[lvl][lay.order[lvl]], np.arange(lay.sizes[lvl]))
+    assert not lay.is_identity(1) and lay.is_identity(0)
+    S = sc.scone_shifts()[0]
+    D = S.device_csr().toarray()
+    P = lay.perm[1]
+    assert np.array_equal(D[np.ix_(P, P)], S.toarray())       # D = P S P^T
+    # locality: a 64-row block of the reordered operator needs far fewer distinct source rows than the input order
+    def ratio(M):
+        M = sp.csr_matrix(M)
+        return np.mean([len(np.unique(M.indices[M.indptr[r]:M.indptr[min(r + 64, M.shape[0])]])) / 64
+                        for r in range(0, M.shape[0] - 64, 64)])
+    assert ratio(S.device_csr()) < 0.75 * ratio(S.csr)
+    # no coordinates -> reverse Cuthill-McKee fallback still yields a valid layout
+    sc2 = SimplicialComplex(g.Complex(cx.n_nodes, cx.edges, cx.faces, None, cx.valid_idxs))
+    assert np.array_equal(np.sort(sc2.layout.order[1]), np.arange(cx.n_edges))
+
+
+def test_hilbert_index_is_a_bijection_on_a_grid():
+    xs, ys = np.meshgrid(np.arange(16), np.arange(16))
+    d = hilbert_index(xs.ravel(), ys.ravel(), order=4)
+    assert np.array_equal(np.sort(d), np.arange(256))
+    o = np.argsort(d)
+    steps = np.abs(np.diff(xs.ravel()[o])) + np.abs(np.diff(ys.ravel()[o]))
+    assert np.all(steps == 1)                                  # consecutive curve points are grid neighbours
+
+
+def test_union_pattern_values(cx):
+    sc = SimplicialComplex(cx)
+    lo, up = (s.device_csr() for s in sc.scone_shifts())
+    rowptr, cols, (v0, v1) = union_pattern([lo, up])
+    U = sp.csr_matrix((v0, cols, rowptr), shape=lo.shape)
+    V = sp.csr_matrix((v1, cols, rowptr), shape=lo.shape)
+    assert np.array_equal(U.toarray(), lo.toarray()) and np.array_equal(V.toarray(), up.toarray())
+    assert len(cols) == lo.nnz                                 # pattern(L_upper) inside pattern(L_lower)
+    for r in range(0, lo.shape[0], 97):
+        c = cols[rowptr[r]:rowptr[r + 1]]
+        assert np.all(np.diff(c) > 0)
+
+
+def test_sparse_flows_roundtrip_and_reference_flow_values(cx, cfg1):
+    X = cfg1["flows"][:40]
+    sf = g.SparseFlows.fromdense(X)
+    assert np.array_equal(sf.todense(), X.astype(np.float32))
+    sub = sf.select(np.array([3, 7, 7, 0]))
+    assert np.array_equal(sub.todense(), X[[3, 7, 7, 0]].astype(np.float32))
+    # path_to_flow semantics (SDG:327-344): +1 along increasing node number, -1 against it
+    path = [int(cx.edges[10, 1]), int(cx.edges[10, 0])]
+    f = g.paths_to_flows(cx, [path]).todense()[0, :, 0]
+    assert f[10] == -1 and np.abs(f).sum() == 1
+
+
+def test_walks_and_dataset_shapes(cx):
+    paths = g.generate_random_walks(cx, m=30, seed=5)
+    assert all(len(p) == len(set(p)) for p in paths)           # simple paths (SDG:239)
+    adj = g.adjacency(cx)
+    for p in paths[:5]:
+        assert all(adj[p[i], p[i + 1]] == 1 for i in range(len(p) - 1))
+    flows, choice, last, tnodes, prefixes = g.path_dataset(cx, paths, seed=1)
+    nbr, deg = g.neighborhood_table(cx)
+    assert len(flows) == 30 and np.all(nbr[last, choice] == tnodes)
+    assert all(pre[-1] == l for pre, l in zip(prefixes, last))
+    assert g.calibrate_n_points(1_000_000) == 369004
+
+
+def test_dataset_folder_roundtrip(tmp_path, monkeypatch):
+    from scone_gcn_amd import dataset_io
+    monkeypatch.chdir(tmp_path)
+    cx = dataset_io.generate_dataset(150, 40, folder="t", holes=True)
+    X, (B1, B2), y, train_mask, test_mask, coords, last, tnodes = dataset_io.load_dataset("trajectory_data_1hop_t")
+    assert X.shape == (40, cx.n_edges, 1) and y.shape[0] == 40 and y.shape[2] == 1
+    assert train_mask.sum() == 32 and np.array_equal(train_mask + test_mask, np.ones(40))
+    sc = SimplicialComplex.from_incidence(B1, B2, coords=coords)
+    assert np.array_equal(sc.cx.edges, cx.edges) and np.array_equal(sc.cx.faces, cx.faces)
+    assert np.all(y.sum(axis=(1, 2)) == 1)
+    X2, _, y2, *_ = dataset_io.load_dataset("trajectory_data_2hop_t")
+    assert np.all(np.abs(X2).sum(axis=(1, 2)) == np.abs(X).sum(axis=(1, 2)) + 1)   # 2-hop prefix has one more edge
+    rev, rt, rl = dataset_io.load_reverse("trajectory_data_1hop_t")
+    assert rev.shape == X.shape and len(rl) == 40
+    # sparse storage path
+    monkeypatch.setattr(dataset_io, "DENSE_LIMIT", 10)
+    dataset_io.generate_dataset(150, 12, folder="s", holes=True)
+    Xs, (B1s, B2s), *_ = dataset_io.load_dataset("trajectory_data_1hop_s")
+    assert isinstance(Xs, g.SparseFlows) and sp.issparse(B1s) and os.path.exists("trajectory_data_1hop_s/B1.npz")
+
+
+def test_hyperparams_parser_matches_reference_flags():
+    from scone_gcn_amd.trajectory_experiments import hyperparams
+    d = hyperparams(["prog"])
+    assert d["model"] == "scone" and d["epochs"] == 1000 and d["learning_rate"] == 0.001 and d["weight_decay"] == 0.00005
+    assert d["batch_size"] == 100 and d["hidden_layers"] == [(3, 16)] * 3 and d["data_folder_suffix"] == "working"
+    d = hyperparams(["prog", "-model", "bunch", "-hidden_layers", "7_32_7_32_7_32", "-epochs", "5", "-flip_edges", "1",
+                     "-model_name", "m1"])
+    assert d["model"] == "bunch" and d["hidden_layers"] == [(7, 32)] * 3 and d["epochs"] == 5.0
+    assert d["flip_edges"] == 1.0 and d["model_name"] == "m1"
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "scone_gcn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/", "").lower() or f == "__init__.py" or \
+                    all("import" not in line for line in src.splitlines() if "oracle" in line.lower()), f
