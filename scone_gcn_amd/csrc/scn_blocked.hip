@@ -1086,13 +1086,15 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
 // thread = (row, trajectory, channel quad); per-thread accumulators reduced once at the end.
 // ------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(BK_THREADS, 2) void bwd_c1_kernel(PlanDev P, const float* __restrict__ DZ,
+__global__ __launch_bounds__(SP_THREADS, 4) void bwd_c1_kernel(PlanDev P, const float* __restrict__ DZ,
                                                                const float* __restrict__ aux,
                                                                float* __restrict__ partial, int n_rows, int n_cols,
                                                                int n_slabs) {
+    // 16 waves, thread = (row, 16-byte chunk) like the dual SpMM: BK_R * CPP <= SP_ITEMS * SP_THREADS items per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = BK_NS * C * 4, CPP = PIECE / 16, CQ = C / 4;
     const Smem sm = carve(smem, PIECE);
+    uint8_t* tws = (uint8_t*)(smem + smem_bytes(PIECE));
     const int tid = threadIdx.x;
     f32x4 acc[3];
     acc[0] = acc[1] = acc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1102,50 +1104,65 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c1_kernel(PlanDev P, const 
     if (slab0 < slab1)
     for (; b < b_end; b += b_stride) {
         wait_all_and_barrier();
-        const BlockMeta m = load_block(P, b, sm);
+        BlockMeta m;
+        {
+            m.row0 = P.blk_row0[b];
+            m.rows = P.blk_rows[b];
+            const int sp0 = P.src_ptr[b];
+            m.nsrc = P.src_ptr[b + 1] - sp0;
+            m.w = P.width[b];
+            const int ep = P.ell_ptr[b];
+            for (int i = tid; i < m.nsrc; i += SP_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
+            for (int i = tid; i < m.w * m.rows; i += SP_THREADS) {
+                sm.slot[i] = P.ell_slot[ep + i];
+                sm.v[i] = P.ell_v[ep + i];
+            }
+            if (tid < BK_R) sm.self[tid] = P.self_slot[(size_t)b * BK_R + tid];
+            if (tid < BK_WAVES) tws[tid] = P.tile_w[b * BK_WAVES + tid];
+        }
         __syncthreads();
-        dma_stage<PIECE, 0>((const char*)DZ + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        dma_stage_sp((const char*)DZ + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc, PIECE, CPP);
         const int total = m.rows * CPP;                           // (row, chunk) pairs; chunk = n*CQ + cq
-        float xn[4];                                              // x of the next slab (fetched one slab ahead)
+        float xn[SP_ITEMS];                                       // x of the next slab (fetched one slab ahead)
         {
             const float* xs = aux + ((size_t)slab0 * n_rows + m.row0) * BK_NS;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = tid + k * BK_THREADS;
+            for (int k = 0; k < SP_ITEMS; ++k) {
+                const int idx = tid + k * SP_THREADS;
                 xn[k] = idx < total ? xs[(idx / CPP) * BK_NS + (idx % CPP) / CQ] : 0.f;
             }
         }
         for (int slab = slab0; slab < slab1; ++slab) {
             const char* cur = sm.buf((slab - slab0) & 1);
             wait_vm_and_barrier();
-            float xv[4];
+            float xv[SP_ITEMS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xv[k] = xn[k];
+            for (int k = 0; k < SP_ITEMS; ++k) xv[k] = xn[k];
             if (slab + 1 < slab1) {
                 const float* xs = aux + ((size_t)(slab + 1) * n_rows + m.row0) * BK_NS;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int idx = tid + k * BK_THREADS;
+                for (int k = 0; k < SP_ITEMS; ++k) {
+                    const int idx = tid + k * SP_THREADS;
                     xn[k] = idx < total ? xs[(idx / CPP) * BK_NS + (idx % CPP) / CQ] : 0.f;
                 }
-                dma_stage<PIECE, 0>((const char*)DZ + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
-                                    m.nsrc);
+                dma_stage_sp((const char*)DZ + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm, m.nsrc,
+                             PIECE, CPP);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                         // BK_R * CPP <= 4 * BK_THREADS
-                const int idx = tid + k * BK_THREADS;
+            for (int k = 0; k < SP_ITEMS; ++k) {
+                const int idx = tid + k * SP_THREADS;
                 if (idx < total) {
                     const int r = idx / CPP, ch = idx - r * CPP;
-                    const int tw = P.tile_w[b * BK_WAVES + (r >> 3)];
+                    const int tw = __builtin_amdgcn_readfirstlane(tws[r >> 3]);   // CPP in {16, 32}: a wave spans <= 4 rows of one group
                     f32x4 gl = {0.f, 0.f, 0.f, 0.f}, gu = gl;
-                    const f32x4 gsv = *(const f32x4*)(cur + sm.self[r] * PIECE + ch * 16);
+                    const char* cb = cur + ch * 16;
+                    const f32x4 gsv = *(const f32x4*)(cb + sm.self[r] * PIECE);
                     const int rb = r * m.w;
-                    EllPair en = ell_load(sm, rb);
+#pragma unroll 2
                     for (int t = 0; t < tw; t += 2) {
-                        const EllPair e = en;
-                        if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
-                        const f32x4 d0 = *(const f32x4*)(cur + e.s0 * PIECE + ch * 16);
-                        const f32x4 d1 = *(const f32x4*)(cur + e.s1 * PIECE + ch * 16);
+                        const EllPair e = ell_load(sm, rb + t);
+                        const f32x4 d0 = *(const f32x4*)(cb + e.s0 * PIECE);
+                        const f32x4 d1 = *(const f32x4*)(cb + e.s1 * PIECE);
                         gl += e.v[0] * d0;
                         gu += e.v[1] * d0;
                         gl += e.v[2] * d1;
@@ -1160,14 +1177,14 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c1_kernel(PlanDev P, const 
     }
     // threads with equal cq = tid % CQ hold the same channels: reduce over them in a fixed order
     wait_all_and_barrier();
-    f32x4* red = (f32x4*)sm.buf(0);                               // [3][BK_THREADS]
+    f32x4* red = (f32x4*)sm.buf(0);                               // [3][SP_THREADS]
 #pragma unroll
-    for (int g = 0; g < 3; ++g) red[g * BK_THREADS + tid] = acc[g];
+    for (int g = 0; g < 3; ++g) red[g * SP_THREADS + tid] = acc[g];
     __syncthreads();
     if (tid < 3 * CQ) {
         const int g = tid / CQ, cq = tid - g * CQ;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int t = cq; t < BK_THREADS; t += CQ) s += red[g * BK_THREADS + t];
+        for (int t = cq; t < SP_THREADS; t += CQ) s += red[g * SP_THREADS + t];
         float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (3 * C) + g * C + cq * 4;
         outp[0] = s[0]; outp[1] = s[1]; outp[2] = s[2]; outp[3] = s[3];
     }
@@ -1274,7 +1291,7 @@ bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz
 static size_t bwd_lds(int cd, int c_aux) {
     if (c_aux == 32) return smem_bytes(512, BK_WAVES * 16 * T32_STRIDE * 4);
     if (c_aux == 16) return smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4);
-    return smem_bytes(BK_NS * cd * 4);
+    return smem_bytes(BK_NS * cd * 4, 16);
 }
 
 size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux) {
@@ -1305,10 +1322,10 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
                            nc, n_slabs, act);
     } else if (cd == 32) {
         SCN_ENSURE_LDS(bwd_c1_kernel<32>, lds);
-        hipLaunchKernelGGL(bwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
+        hipLaunchKernelGGL(bwd_c1_kernel<32>, grid, dim3(SP_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
     } else {
         SCN_ENSURE_LDS(bwd_c1_kernel<16>, lds);
-        hipLaunchKernelGGL(bwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
+        hipLaunchKernelGGL(bwd_c1_kernel<16>, grid, dim3(SP_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);
     }
     SCN_LAUNCH_CHECK();
     const int per = c_aux * 3 * cd;
