@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--per-gpu-batch", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=4, help="trajectories in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--spmm", type=int, default=1, help="also time the standalone dual SpMM (reported as extra)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")
     return ap.parse_args()
 
 
@@ -76,10 +77,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     from scone_gcn_amd import ops
     from scone_gcn_amd import scone_trajectory_model as stm
@@ -124,7 +130,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -152,9 +158,17 @@ def main():
     dom = max((k for k in tot if alg_bytes(k) is not None), key=lambda k: tot[k])
     n_launch, ms = ksum[dom]
     achieved = alg_bytes(dom) / (ms * 1e-3)
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/; same |E|, hidden and launch size only)
+    traffic = None
+    kmap = {"conv_bwd c32->32": "scn::bwd_c32_kernel", "conv_fwd c32->32": "scn::fwd_c32_kernel",
+            "conv_fwd c1->32": "scn::fwd_c1_kernel", "conv_bwd c32->1 (dW only)": "scn::bwd_c1_kernel"}
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tfile) and dom in kmap and E == 996634 and mb == 128:
+        traffic = json.load(open(tfile)).get(kmap[dom], {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None, "launch_ms": ms, "launches_per_step": n_launch,
-                "algorithmic_bytes_per_launch": alg_bytes(dom), "units_per_launch": mb}
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "launch_ms": ms, "launches_per_step": n_launch,
+                "algorithmic_bytes_per_launch": alg_bytes(dom), "units_per_launch": mb,
+                "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE+WRITE_SIZE per launch)" if traffic else None}
     kernels = {k: {"launches": n, "avg_ms": ms_, "GB/s": (alg_bytes(k) / (ms_ * 1e-3) / 1e9) if alg_bytes(k) else None}
                for k, (n, ms_) in ksum.items()}
 

@@ -29,7 +29,13 @@ def shard_indices(idx, rank, world_size):
 def all_reduce_sum_(flat, group=None):
     """In-place sum of the flat gradient buffer over ranks (no-op for a single process)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal on a box without RCCL peers: gloo reduces a host copy (tiny: the flat gradient buffer)
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 

@@ -23,7 +23,17 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
         for (int i = 0; i < iters; ++i) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {   // 16 * 4 float4 fma = 64 v_fma lanes-instrs (32 pk) per iteration
+#ifdef SCALAR_FMA
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x0[j]) : "v"(b), "v"(x1[j]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x1[j]) : "v"(b), "v"(x2[j]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x2[j]) : "v"(b), "v"(x3[j]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x3[j]) : "v"(b), "v"(x0[j]));
+                }
+#else
                 x0 = x0 * b + x1; x1 = x1 * b + x2; x2 = x2 * b + x3; x3 = x3 * b + x0;
+#endif
             }
         }
         res = x0[0] + x1[1] + x2[2] + x3[3];
