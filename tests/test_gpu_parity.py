@@ -272,3 +272,58 @@ def test_errors_are_loud(cfg1, sc1):
         te.scone_func(w[:-2], *shifts, readout, cfg1["last_nodes"][:4], cfg1["flows"][:4])   # wrong number of weights
     with pytest.raises(ValueError):
         te.scone_func(w, *shifts, readout, cfg1["last_nodes"][:3], cfg1["flows"][:4])
+
+
+def test_ocean_drifter_config_full_batch():
+    """BASELINE.json config 3: buoy complex (133 nodes / 320 edges / 186 faces), 3-layer SCoNe hidden 16, all 160
+    training trajectories as one batch: loss, every gradient and test-set accuracy against the oracle."""
+    _need_gpu()
+    import os
+    from scone_gcn_amd import buoy_data as bd
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "buoy.npz"))
+    trajs = [gld["traj_nodes"][gld["traj_ptr"][i]:gld["traj_ptr"][i + 1]].astype(int).tolist()
+             for i in range(len(gld["traj_ptr"]) - 1)]
+    cx, paths, flows, choice, last, tnodes, train_mask, test_mask = bd.buoy_dataset(
+        gld["elist"].astype(np.int64), gld["tlist"].astype(np.int64), gld["coords"], trajs)
+    sc = SimplicialComplex(cx)
+    D = sc.max_degree
+    y = so.onehot_targets(choice, D)
+    w = _rand_weights(so.weight_shapes(1, [(3, 16)] * 3, 1), 0.3, 13)
+    B1, B2 = (m.toarray() for m in g.incidence_matrices(cx))
+    L_lo, L_up = so.scone_shifts(B1, B2)
+    nb, _ = so.neighborhoods(cx.edges, cx.n_nodes)
+    X = flows.todense().astype(np.float64)
+    ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, so.make_Bconds(B1, nb), last, X, y, train_mask, 0.0)
+    ref_out = so.scone_forward(w, L_lo, L_up, so.make_Bconds(B1, nb), last, X)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.scone_func(wt, *shifts, readout, last, flows)
+    assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
+    m = torch.as_tensor(train_mask, device="cuda").bool()
+    loss = -(out[m] * torch.as_tensor(y, dtype=torch.float32, device="cuda")[m]).sum() / m.sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL
+    n_nbrs = sc.n_nbrs(last)
+    acc_ref = so.accuracy_from_preds(ref_out, y, test_mask, n_nbrs)
+    acc = so.accuracy_from_preds(out.detach().cpu().numpy().astype(np.float64), y, test_mask, n_nbrs)
+    assert acc == acc_ref
+
+
+def test_isolated_last_node_and_empty_flow(cfg1, sc1):
+    """Edge cases: a trajectory whose last node has no neighbours (all -1 padding -> uniform log-probs -log D) and an
+    all-zero flow (every activation stays exactly zero: no bias terms, TE:145-149)."""
+    from scone_gcn_amd import trajectory_experiments as te
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    iso = int(np.nonzero((nb >= 0).sum(1) == 0)[0][0])
+    w = _rand_weights(so.weight_shapes(1, [(3, 16)] * 3, 1), 0.25, 17)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    X = np.zeros((2, cfg1["E"], 1))
+    X[0] = cfg1["flows"][3]
+    out = te.scone_func(w, *shifts, readout, np.array([iso, int(cfg1["last_nodes"][3])]), X).cpu().numpy()
+    assert np.allclose(out[0, :, 0], -np.log(D), atol=1e-6)
+    assert np.allclose(out[1, :, 0], -np.log(D), atol=1e-6)          # zero flow -> zero logits everywhere

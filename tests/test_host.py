@@ -168,3 +168,35 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").lower() or f == "__init__.py" or \
                     all("import" not in line for line in src.splitlines() if "oracle" in line.lower()), f
+
+
+def _buoy():
+    from scone_gcn_amd import buoy_data as bd
+    gld = np.load(os.path.join(GOLDEN, "buoy.npz"))
+    trajs = [gld["traj_nodes"][gld["traj_ptr"][i]:gld["traj_ptr"][i + 1]].astype(int).tolist()
+             for i in range(len(gld["traj_ptr"]) - 1)]
+    return bd.buoy_dataset(gld["elist"].astype(np.int64), gld["tlist"].astype(np.int64), gld["coords"], trajs)
+
+
+def test_ocean_drifter_dataset_counts():
+    """Config 3 (BASELINE.json): the numbers SURVEY.md section 2 row 10 measured with the reference's converter rules."""
+    cx, paths, flows, choice, last, tnodes, train_mask, test_mask = _buoy()
+    assert (cx.n_nodes, cx.n_edges, cx.n_faces) == (133, 320, 186)
+    assert len(paths) == 200 and train_mask.sum() == 160 and test_mask.sum() == 40
+    assert all(5 - 0 <= len(p) <= 10 for p in paths)
+    nbr, deg = g.neighborhood_table(cx)
+    assert nbr.shape[1] == 6 and abs(deg.mean() - 4.8) < 0.05
+    assert np.all(nbr[last, choice] == tnodes)
+    B1, B2 = g.incidence_matrices(cx)
+    assert abs(B1 @ B2).max() == 0
+
+
+def test_jld2_reader_on_reference_file_if_present():
+    path = "/root/reference/ocean_drifters_data/dataBuoys.jld2"
+    if not os.path.exists(path):
+        pytest.skip("reference data file not on this machine")
+    from scone_gcn_amd import buoy_data as bd
+    elist, tlist, coords, trajs = bd.read_buoy_file(path)
+    gld = np.load(os.path.join(GOLDEN, "buoy.npz"))
+    assert np.array_equal(elist, gld["elist"]) and np.array_equal(tlist, gld["tlist"]) and len(trajs) == 339
+    assert bd.strip_paths([[1, 2, 1, 3, 4, 3, 5]]) == [[1, 3, 5]]
