@@ -1014,6 +1014,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* patch = (float*)(smem + smem_bytes(PIECE)) + wave * (16 * T32_STRIDE);
     const int p = lane & 31, h = lane >> 5, n = p & 3, rt = wave * 8 + (p >> 2);
+    STAMP_DECL;
     // dgrad B operands: k-step s of segment g contracts dz channel 16*h + s against W_g[ca = p][c]
     float Bt[3][16];
 #pragma unroll
@@ -1064,7 +1065,12 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
             const float* ap = aux + (rows_left > 0 ? tuni : 0);   // waves without rows read (and discard) element 0
             float* dp = dx ? dx + tuni : nullptr;
             const int L0 = p + 128 * h;                       // lane part of the element offset: pt*32 + p
-            wait_vm_and_barrier();
+            STAMP_START();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP_ADD(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP_ADD(1);
             f32x4 gs[4], gl[4], gu[4];
             {
                 const int slot = sm.self[rtc];
@@ -1099,6 +1105,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
                     }
                 }
             }
+            STAMP_ADD(2);
             // dgrad chain: dH[point][ca] = sum_k G[point][k] * W[ca][k]   (D: column = lane&31 = ca, rows = points).
             // Vector-memory issue rides inside the chain (the wave sits on the accumulator dependency anyway):
             // first the LDS-DMA of the next slab, then this tile's 16 aux values (used right after the chain).
@@ -1127,6 +1134,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
                     }
                 }
             }
+            STAMP_ADD(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(act, a[r]);
             // dW_g += aux^T G_g : A[i = ca][k = point] = a[s], B[k = point][j = c] = G_g[pt(s,h)][c = p].
@@ -1156,8 +1164,10 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
                     wave_lds_sync();
                 }
             }
+            STAMP_ADD(4);
         }
     }
+    STAMP_FLUSH();
     // reduce the eight waves' dW tiles in a fixed order and emit this workgroup's partial [ca][slot*32 + c]
     wait_all_and_barrier();
     float* red = (float*)sm.buf(0);                             // 8 waves * 3072 floats = 96 KB (both stage buffers)

@@ -13,13 +13,20 @@ plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_dev
 E, C, S = cx.n_edges, 32, 32
 W = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
 x = torch.randn(S, E, 4, C, device="cuda")
-plan.conv.forward([x], W, C, "tanh"); torch.cuda.synchronize()
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+os.environ["SCN_F32_MFMA"] = "1"       # the stamps live in the fp32-MFMA forward kernel
+def run():
+    if which == "fwd":
+        plan.conv.forward([x], W, C, "tanh")
+    else:
+        plan.conv.backward([x], W, x, "tanh", True, [torch.zeros_like(w) for w in W])
+run(); torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8)()
 lib.scn_debug_stamps = ctypes.CDLL(os.environ["SCN_LIB_PATH"]).scn_debug_stamps
 lib.scn_debug_stamps(buf, 1)
-plan.conv.forward([x], W, C, "tanh"); torch.cuda.synchronize()
+run(); torch.cuda.synchronize()
 lib.scn_debug_stamps(buf, 0)
-names = ["wait vmcnt(0)", "barrier", "dma issue", "stores", "gather", "mfma+epilogue"]
+names = ["wait vmcnt(0)", "barrier", "dma issue", "stores", "gather", "mfma+epilogue"] if which == "fwd" else ["wait vmcnt(0)", "barrier", "gather", "dgrad chain", "epilogue+dW", "-"]
 waves = buf[7]; tot = sum(buf[i] for i in range(6))
 iters = 16505 * 32 * 8 / max(waves, 1)
 print("waves", waves, "slab iterations per wave %.0f" % iters)
