@@ -437,7 +437,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const
                                                                 const float* __restrict__ W1,
                                                                 const float* __restrict__ W2,
                                                                 float* __restrict__ out, int n_rows, int n_cols,
-                                                                int n_slabs, int dbg) {
+                                                                int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;   // 8 LDS-DMA instructions per wave
     const Smem sm = carve(smem, PIECE);
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const
         wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
         __syncthreads();
-        const int tw = (dbg & 1) ? 0 : P.tile_w[b * BK_WAVES + wave];
+        const int tw = P.tile_w[b * BK_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
         // per-lane source offsets of this wave's LDS-DMA instructions (the same for every slab of the block)
         uint32_t goff[NDMA];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const
                 const f32x16 prev = pend;
                 float* const prev_ptr = pend_ptr;
                 const bool prev_valid = pend_valid && pend_ptr != nullptr;
-                const bool more = slab + 1 < slab1 && !(dbg & 4);
+                const bool more = slab + 1 < slab1;
                 const char* Xn = (const char*)X + (size_t)(slab + 1) * slab_bytes;
                 char* nbuf = sm.buf((slab + 1 - slab0) & 1);
                 c32_mfma_epilogue<ACT>(zs, zl, zu, Bw, pend, [&](int k) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c32_kernel(PlanDev P, const
                         if (more && base + lane < total)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
                                                              (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
-                    } else if (prev_valid && !(dbg & 8)) {
+                    } else if (prev_valid) {
                         const int g = k - NDMA;
                         *(f32x4*)(prev_ptr + 8 * g) = f32x4{prev[4 * g], prev[4 * g + 1], prev[4 * g + 2], prev[4 * g + 3]};
                     }
@@ -1480,8 +1480,6 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
     const int ci = c_in[0];
     const int nr = c->n_rows, nc = c->g[0].n_cols;
     if (ci == 32) {
-        const char* dbg_env = getenv("SCN_DBG");
-        const int dbg = dbg_env ? atoi(dbg_env) : 0;
         const size_t lds = smem_bytes(512);
         SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_NONE>, lds);
         SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_TANH>, lds);
@@ -1490,7 +1488,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
         launch_grid(c, n_slabs, lds, grid);
 #define SCN_LAUNCH_FWD32(A)                                                                                       \
     hipLaunchKernelGGL(fwd_c32_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc, \
-                       n_slabs, dbg)
+                       n_slabs)
         static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
         if (!f32_mfma) {                                                   // default: the 16-wave bf16x3 kernel
             const size_t lds16 = smem_bytes(512, W16_WFRAG_BYTES + 16);

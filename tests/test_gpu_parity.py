@@ -327,3 +327,41 @@ def test_isolated_last_node_and_empty_flow(cfg1, sc1):
     out = te.scone_func(w, *shifts, readout, np.array([iso, int(cfg1["last_nodes"][3])]), X).cpu().numpy()
     assert np.allclose(out[0, :, 0], -np.log(D), atol=1e-6)
     assert np.allclose(out[1, :, 0], -np.log(D), atol=1e-6)          # zero flow -> zero logits everywhere
+
+
+def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
+    """Scone_GCN.train (STM:264-357) end to end: same seed-1030 weight / batch-mask stream, two epochs of Adam steps,
+    final weights, returned losses and accuracies against an oracle trainer; then test() and two_target_accuracy()."""
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    stm.reseed(1030)
+    N, bs, epochs = 120, 30, 2
+    sel = np.arange(N)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    inputs = [readout, cfg1["last_nodes"][sel], cfg1["flows"][sel]]
+    y, train_mask, test_mask = cfg1["targets"][sel], cfg1["train_mask"][sel], cfg1["test_mask"][sel]
+    n_nbrs = sc1.n_nbrs(inputs[1])
+    net = stm.Scone_GCN(epochs, 1e-3, bs, 5e-5, verbose=False)
+    net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, train_mask, model_type="scone")
+    res = net.train(inputs, y, train_mask, test_mask, n_nbrs)
+
+    rs = np.random.RandomState(1030)
+    w = [(0.01 * rs.randn(*s)).astype(np.float32).astype(np.float64) for s in so.weight_shapes(1, [(3, 16)] * 3, 1)]
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, "scone")
+    adam = so.Adam(w, 1e-3)
+    n_batches = int(train_mask.sum()) // bs
+    for i in range(epochs * n_batches):
+        bm = so.draw_batch_mask(rs, N, bs, train_mask)
+        _, g = so.scone_loss_and_grad(adam.x, shifts_o[0], shifts_o[1], Bc, inputs[1], X, y, bm, 5e-5)
+        adam.update(i, g)
+    for a, b in zip(net.weights, adam.x):
+        assert _maxdiff(a.cpu().numpy(), b) <= 5e-6
+    out = so.scone_forward(adam.x, shifts_o[0], shifts_o[1], Bc, inputs[1], X)
+    ref = (so.loss_from_preds(out, y, train_mask, adam.x, 5e-5), so.accuracy_from_preds(out, y, train_mask, n_nbrs),
+           so.loss_from_preds(out, y, test_mask, adam.x, 5e-5), so.accuracy_from_preds(out, y, test_mask, n_nbrs))
+    assert abs(res[0] - ref[0]) <= 1e-5 and abs(res[2] - ref[2]) <= 1e-5
+    assert res[1] == ref[1] and res[3] == ref[3]
+    loss, acc = net.test(inputs, y, test_mask, n_nbrs)
+    assert abs(loss - ref[2]) <= 1e-5 and acc == ref[3]
+    t2 = net.two_target_accuracy(shifts, inputs, y, test_mask, n_nbrs)
+    assert 0.0 <= t2 <= 1.0
