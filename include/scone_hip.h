@@ -116,6 +116,19 @@ int scn_conv_backward(scn_conv_t conv_t, int32_t n_slabs, int32_t ns,
 int scn_spmm_dual(scn_conv_t conv, int32_t n_slabs, int32_t k,
                   const float* x, float* ya, float* yb, void* stream);
 
+/* Dense contraction over already-gathered terms of one Bunch level (TE:184-195 once the S_k X products exist):
+ *   forward : out[p,:] = act( sum_k G[k][p,:] @ W[k] ),  G[k] device [n_points][c_in[k]], W[k] device [c_in[k]][c_out]
+ *   backward: dx[p,:] = ( sum_k G[k][p,:] @ W[k]^T ) * act'(aux[p,:]) ; dW[k] += sum_p aux[p,:]^T G[k][p,:]
+ *             with G[k] = S_k^T dZ device [n_points][c[k]], W[k] device [c_aux][c[k]] (forward weights), aux = this
+ *             level's forward input [n_points][c_aux]; dx may be NULL; deterministic reduction order.
+ * n_points counts every (slab, row, trajectory) of the level; n_terms <= 3.                                        */
+int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* const* G, const int32_t* c_in,
+                            const float* const* W, int32_t c_out, int32_t act, float* out, void* stream);
+size_t scn_dense_terms_backward_workspace(int64_t n_points, int32_t n_terms, const int32_t* c, int32_t c_aux);
+int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* const* G, const int32_t* c,
+                             const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
+                             float* const* dW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Readout (TE:151-152 with Bconds_func TE:298-303, B1_jax TE:288, nbrhoods TE:279):
  *   logits[n,d] = sum_{e incident to v} sign(v,e) * (H[e,n,:] . w_last),  v = nbr[last[n]][d];  v = -1 -> 0

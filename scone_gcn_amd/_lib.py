@@ -40,6 +40,12 @@ SIGNATURES = {
                                          ctypes.POINTER(c_void_p), c_void_p, c_i32, c_i32, c_void_p,
                                          ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "scn_spmm_dual": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "scn_dense_terms_forward": (ctypes.c_int, [c_i64, c_i32, ctypes.POINTER(c_void_p), P_i32, ctypes.POINTER(c_void_p), c_i32,
+                                               c_i32, c_void_p, c_void_p]),
+    "scn_dense_terms_backward_workspace": (c_size_t, [c_i64, c_i32, P_i32, c_i32]),
+    "scn_dense_terms_backward": (ctypes.c_int, [c_i64, c_i32, ctypes.POINTER(c_void_p), P_i32, ctypes.POINTER(c_void_p),
+                                                c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+                                                c_size_t, c_void_p]),
     "scn_readout_forward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),

@@ -189,11 +189,17 @@ class SimplicialComplex:
         orders = [None, None, None]
         if reorder and cx.n_edges > 1:
             if cx.coords is not None:
+                orders[0] = _hilbert_order(cx.coords[:cx.n_nodes])
                 mid = 0.5 * (cx.coords[cx.edges[:, 0]] + cx.coords[cx.edges[:, 1]])
                 orders[1] = _hilbert_order(mid)
+                if cx.n_faces > 1:
+                    orders[2] = _hilbert_order(cx.coords[cx.faces].mean(axis=1))
             else:
-                L = (self.B1.T @ self.B1).tocsr()
-                orders[1] = np.asarray(reverse_cuthill_mckee(L, symmetric_mode=True), np.int64)
+                rcm = lambda M: np.asarray(reverse_cuthill_mckee(sp.csr_matrix(M), symmetric_mode=True), np.int64)
+                orders[0] = rcm(self.B1 @ self.B1.T)
+                orders[1] = rcm(self.B1.T @ self.B1)
+                if cx.n_faces > 1:
+                    orders[2] = rcm(self.B2.T @ self.B2)
         self.layout = Layout((cx.n_nodes, cx.n_edges, cx.n_faces), orders)
 
     @classmethod

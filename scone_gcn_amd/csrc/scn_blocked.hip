@@ -65,9 +65,12 @@ static int upload(scn_conv_s* c, const std::vector<T>& h, const T** out) {
 
 int build_block_plan(scn_conv_s* c) {
     // only the scone/ebli shape gets a plan; everything else runs the generic kernels
+    // single-group operators get a plan: identity + 2 value arrays is the scone/ebli layer (MFMA kernels); one value
+    // array without identity is a bare shift (Bunch terms) served by the blocked SpMM
     if (c->n_groups != 1) return SCN_OK;
     const Group& G = c->g[0];
-    if (!(G.identity == 1 && G.n_vals == 2)) return SCN_OK;
+    if (G.n_vals < 1) return SCN_OK;
+    const bool has_v1 = G.n_vals > 1, has_id = G.identity == 1;
     const int n_rows = c->n_rows;
     std::vector<int32_t> blk_row0, src_ptr(1, 0), src_rows, ell_ptr;
     std::vector<uint8_t> blk_rows, width, tile_w, ell_slot, self_slot;
@@ -86,7 +89,7 @@ int build_block_plan(scn_conv_s* c) {
             int add = 0;
             for (int j = j0; j < j1; ++j)
                 if (mark[G.h_col[j]] != bid) ++add;
-            bool self_new = mark[r] != bid;
+            bool self_new = has_id && mark[r] != bid;
             for (int j = j0; j < j1 && self_new; ++j)
                 if (G.h_col[j] == r) self_new = false;
             if (self_new) ++add;
@@ -94,7 +97,7 @@ int build_block_plan(scn_conv_s* c) {
             if ((int)cur.size() + add > BK_SRC || nw * (rows + 1) > BK_ELL_CAP || nw > 254) break;
             for (int j = j0; j < j1; ++j)
                 if (mark[G.h_col[j]] != bid) { mark[G.h_col[j]] = bid; cur.push_back(G.h_col[j]); }
-            if (mark[r] != bid) { mark[r] = bid; cur.push_back(r); }
+            if (has_id && mark[r] != bid) { mark[r] = bid; cur.push_back(r); }
             w = nw;
             ++rows;
         }
@@ -121,10 +124,10 @@ int build_block_plan(scn_conv_s* c) {
                 for (int j = j0; j < j1; ++j) {
                     const size_t e = base + (size_t)i * w + (j - j0);
                     ell_slot[e] = (uint8_t)local[G.h_col[j]];
-                    ell_v[e] = float2{G.h_val0[j], G.h_val1[j]};
+                    ell_v[e] = float2{G.h_val0[j], has_v1 ? G.h_val1[j] : 0.f};
                 }
                 tw[i >> 3] = std::max<uint8_t>(tw[i >> 3], (uint8_t)((j1 - j0 + 1) & ~1));
-                ss = (uint8_t)local[r];
+                ss = has_id ? (uint8_t)local[r] : 0;
             }
             self_slot.push_back(ss);
         }
@@ -1588,7 +1591,7 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
 }
 
 bool blocked_spmm_supported(const scn_conv_s* c, int k) {
-    return scone_shape(c) && k % 4 == 0 && k >= 4 && k <= 128;
+    return c->plan.built && c->n_groups == 1 && k % 4 == 0 && k >= 4 && k <= 128;
 }
 
 int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st) {

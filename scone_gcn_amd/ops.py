@@ -168,6 +168,35 @@ class ConvOp:
         return ya, yb
 
 
+def dense_terms_forward(Gs, Ws, c_out, act):
+    """out[p,:] = act(sum_k G_k[p,:] @ W_k) over slab tensors [S, rows, ns, c_k] (scn_dense_terms_forward)."""
+    lib = _lib.load()
+    S, R, ns = Gs[0].shape[:3]
+    out = torch.empty((S, R, ns, c_out), device=Gs[0].device, dtype=torch.float32)
+    with _timed("dense_fwd x%d ->%d" % (len(Gs), c_out)):
+        check(lib.scn_dense_terms_forward(S * R * ns, len(Gs), ptr_array([_dev(g).value for g in Gs]),
+                                          i32_array([g.shape[3] for g in Gs]), ptr_array([_dev(w).value for w in Ws]),
+                                          c_out, ACT[act], _dev(out), _stream()), "scn_dense_terms_forward")
+    return out
+
+
+def dense_terms_backward(Gs, Ws, aux, act, need_dx, dWs):
+    lib = _lib.load()
+    S, R, ns, c_aux = aux.shape
+    cs = i32_array([g.shape[3] for g in Gs])
+    n_points = S * R * ns
+    nbytes = lib.scn_dense_terms_backward_workspace(n_points, len(Gs), cs, c_aux)
+    ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
+    dx = torch.empty_like(aux) if need_dx else None
+    with _timed("dense_bwd x%d" % len(Gs)):
+        check(lib.scn_dense_terms_backward(n_points, len(Gs), ptr_array([_dev(g).value for g in Gs]), cs,
+                                           ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
+                                           _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
+                                           ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              "scn_dense_terms_backward")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------
 # slabs
 # ----------------------------------------------------------------------------------------------
@@ -332,8 +361,10 @@ BUNCH_DST = [0, 0, 1, 1, 1, 2, 2]      # output level of weight slot k
 
 
 class BunchPlan:
-    """Device state of the Bunch (SCCONV) model: one conv operator per output level (forward) and one per input
-    level built from the transposed shifts (backward)."""
+    """Device state of the Bunch (SCCONV) model.  Each of the seven shifts S_k (and its transpose for the backward) is a
+    single-operator ConvOp served by the LDS-blocked SpMM; the per-level sum over shifts, the weights and the relu are
+    one dense kernel (scn_dense_terms_*).  Shapes the blocked SpMM does not take (ns*C > 128) fall back to the generic
+    multi-group kernels (one operator per output / input level)."""
 
     def __init__(self, shifts, nbrhoods, device):
         assert len(shifts) == 7 and all(isinstance(s, Shift) for s in shifts)
@@ -341,24 +372,40 @@ class BunchPlan:
         self.device = device
         self.sizes = self.layout.sizes
         dev = [s.device_csr() for s in shifts]
-        self.fwd, self.fwd_slots = [], []
-        self.bwd, self.bwd_slots = [], []
-        for lvl in range(3):
-            ks = [k for k in range(7) if BUNCH_DST[k] == lvl]
-            self.fwd_slots.append(ks)
-            self.fwd.append(ConvOp(self.sizes[lvl], [{"mats": [dev[k]], "identity": False,
-                                                      "n_cols": self.sizes[BUNCH_SRC[k]]} for k in ks]))
-            ks = [k for k in range(7) if BUNCH_SRC[k] == lvl]
-            self.bwd_slots.append(ks)
-            self.bwd.append(ConvOp(self.sizes[lvl], [{"mats": [dev[k].T.tocsr()], "identity": False,
-                                                      "n_cols": self.sizes[BUNCH_DST[k]]} for k in ks]))
+        self.term_fwd = [ConvOp(self.sizes[BUNCH_DST[k]], [{"mats": [dev[k]], "identity": False,
+                                                           "n_cols": self.sizes[BUNCH_SRC[k]]}]) for k in range(7)]
+        self.term_bwd = [ConvOp(self.sizes[BUNCH_SRC[k]], [{"mats": [dev[k].T.tocsr()], "identity": False,
+                                                           "n_cols": self.sizes[BUNCH_DST[k]]}]) for k in range(7)]
+        self.fwd_slots = [[k for k in range(7) if BUNCH_DST[k] == lvl] for lvl in range(3)]
+        self.bwd_slots = [[k for k in range(7) if BUNCH_SRC[k] == lvl] for lvl in range(3)]
+        self._dev_csr = dev
+        self._generic = None
         nb = np.asarray(nbrhoods)
         pn = self.layout.perm[0]
-        nbd = np.where(nb >= 0, pn[np.maximum(nb, 0)], -1)
-        if not self.layout.is_identity(0):
-            raise NotImplementedError("node reordering is not used by the bunch readout (-1 wraps to node V-1)")
+        # padding index -1 wraps to the LAST node of the caller's numbering (TE:201); resolve it here, in device order
+        nbd = np.where(nb >= 0, pn[np.maximum(nb, 0)], pn[self.sizes[0] - 1])
         self.nbr = torch.from_numpy(np.ascontiguousarray(nbd, np.int32)).to(device)
         self.max_deg = nb.shape[1]
+
+    def _generic_ops(self):
+        if self._generic is None:
+            dev = self._dev_csr
+            fwd = [ConvOp(self.sizes[lvl], [{"mats": [dev[k]], "identity": False, "n_cols": self.sizes[BUNCH_SRC[k]]}
+                                            for k in self.fwd_slots[lvl]]) for lvl in range(3)]
+            bwd = [ConvOp(self.sizes[lvl], [{"mats": [dev[k].T.tocsr()], "identity": False,
+                                             "n_cols": self.sizes[BUNCH_DST[k]]} for k in self.bwd_slots[lvl]])
+                   for lvl in range(3)]
+            self._generic = (fwd, bwd)
+        return self._generic
+
+    @staticmethod
+    def _blocked_ok(ns, c):
+        return (ns * c) % 4 == 0 and ns * c <= 128
+
+    def _spmm(self, op, x):
+        S, R, ns, c = x.shape
+        y, _ = op.spmm_dual(x.view(S, R, ns * c), dual=False)
+        return y.view(S, op.n_rows, ns, c)
 
     def conv_stack(self, x, weights):
         n_layers = len(weights) / 7
@@ -366,15 +413,31 @@ class BunchPlan:
         S, E, ns, _ = x.shape
         cur = [torch.zeros((S, self.sizes[0], ns, 1), device=x.device), x,
                torch.zeros((S, self.sizes[2], ns, 1), device=x.device)]         # TE:179
-        states = [cur]
+        zero = [True, False, True]          # levels known to be identically zero (no bias terms: zeros stay zeros)
+        states, zeros = [cur], [zero]
         for i in range(int(n_layers)):
-            nxt = []
+            nxt, nzero = [], []
             for lvl in range(3):
-                ks = self.fwd_slots[lvl]
+                ks = [k for k in self.fwd_slots[lvl] if not zero[BUNCH_SRC[k]]]
+                c_out = weights[7 * i + self.fwd_slots[lvl][0]].shape[1]
+                if not ks:
+                    nxt.append(torch.zeros((S, self.sizes[lvl], ns, c_out), device=x.device))
+                    nzero.append(True)
+                    continue
                 Ws = [weights[7 * i + k] for k in ks]
-                nxt.append(self.fwd[lvl].forward([cur[BUNCH_SRC[k]] for k in ks], Ws, Ws[0].shape[1], "relu"))
-            cur = nxt
+                if all(self._blocked_ok(ns, cur[BUNCH_SRC[k]].shape[3]) for k in ks):
+                    Gs = [self._spmm(self.term_fwd[k], cur[BUNCH_SRC[k]]) for k in ks]
+                    nxt.append(dense_terms_forward(Gs, Ws, c_out, "relu"))
+                else:
+                    fwd, _ = self._generic_ops()
+                    allk = self.fwd_slots[lvl]
+                    nxt.append(fwd[lvl].forward([cur[BUNCH_SRC[k]] for k in allk], [weights[7 * i + k] for k in allk],
+                                                c_out, "relu"))
+                nzero.append(False)
+            cur, zero = nxt, nzero
             states.append(cur)
+            zeros.append(zero)
+        self._zeros = zeros
         return states
 
     def forward(self, x, last_dev, weights):
@@ -388,26 +451,44 @@ class BunchPlan:
         check(lib.scn_node_readout_forward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
                                            _dev(last_dev, torch.int32), _dev(logits), _dev(logp), _stream()),
               "scn_node_readout_forward")
-        return logp, states
+        return logp, (states, self._zeros)
 
-    def backward(self, states, logp, d_logp, last_dev, weights, grads):
+    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         lib = _lib.load()
+        states, zeros = saved
         nodes_out = states[-1][0]
         S, V, ns, _ = nodes_out.shape
-        dz = [torch.empty_like(nodes_out), torch.zeros_like(states[-1][1]), torch.zeros_like(states[-1][2])]
+        dz = [torch.empty_like(nodes_out), None, None]
+        dzero = [False, True, True]             # only the node level feeds the loss (TE:198)
         check(lib.scn_node_readout_backward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
                                             _dev(last_dev, torch.int32), _dev(d_logp.contiguous()), _dev(logp),
                                             ACT["relu"], _dev(dz[0]), _stream()), "scn_node_readout_backward")
         L = len(states) - 1
         for i in reversed(range(L)):
-            x = states[i]
-            new_dz = [None, None, None]
+            x, xzero = states[i], zeros[i]
+            new_dz, new_zero = [None, None, None], [True, True, True]
             for lvl in range(3):
-                ks = self.bwd_slots[lvl]
+                ks = [k for k in self.bwd_slots[lvl] if not dzero[BUNCH_DST[k]]]
+                if not ks or xzero[lvl]:
+                    # a zero input level receives no weight gradient; its own gradient is only needed below layer 0
+                    if i > 0 and ks and xzero[lvl]:
+                        raise AssertionError("zero level above the first layer")
+                    continue
                 Ws = [weights[7 * i + k] for k in ks]
                 dWs = [grads[7 * i + k] for k in ks]
-                new_dz[lvl] = self.bwd[lvl].backward([dz[BUNCH_DST[k]] for k in ks], Ws, x[lvl], "relu", i > 0, dWs)
-            dz = new_dz
+                if all(self._blocked_ok(ns, dz[BUNCH_DST[k]].shape[3]) for k in ks):
+                    Gs = [self._spmm(self.term_bwd[k], dz[BUNCH_DST[k]]) for k in ks]
+                    new_dz[lvl] = dense_terms_backward(Gs, Ws, x[lvl], "relu", i > 0, dWs)
+                else:
+                    _, bwd = self._generic_ops()
+                    allk = self.bwd_slots[lvl]
+                    dzs = [dz[BUNCH_DST[k]] if not dzero[BUNCH_DST[k]]
+                           else torch.zeros((S, self.sizes[BUNCH_DST[k]], ns, weights[7 * i + k].shape[1]), device=x[lvl].device)
+                           for k in allk]
+                    new_dz[lvl] = bwd[lvl].backward(dzs, [weights[7 * i + k] for k in allk], x[lvl], "relu", i > 0,
+                                                    [grads[7 * i + k] for k in allk])
+                new_zero[lvl] = False
+            dz, dzero = new_dz, new_zero
         return grads
 
 

@@ -134,7 +134,7 @@ def test_flip_invariance_tanh(cfg1, sc1):
     assert _maxdiff(outs[("scone", True)], ref) <= TOL
 
 
-@pytest.mark.parametrize("hidden", [8, 16])
+@pytest.mark.parametrize("hidden", [8, 16, 32, 40])   # 40: ns*C > 128 -> generic multi-group kernels
 def test_bunch_matches_oracle(cfg1, sc1, hidden):
     from scone_gcn_amd import trajectory_experiments as te
     sel = np.arange(200, 214)
@@ -262,6 +262,88 @@ def test_larger_synthetic_complex_against_csr_oracle():
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL
+
+
+def test_dense_terms_kernels_match_numpy():
+    """scn_dense_terms_forward/backward (the Bunch per-level contraction) against fp64 NumPy."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    rs = np.random.RandomState(3)
+    for cs, c_out, c_aux, act in (([1, 1], 8, 1, "relu"), ([16, 16, 16], 16, 16, "relu"), ([32, 32], 32, 32, "tanh"),
+                                  ([8, 8, 8], 1, 8, "none"), ([5, 3], 7, 5, "leaky_relu")):
+        S, R, ns = 3, 157, 4
+        Gs = [rs.randn(S, R, ns, c) for c in cs]
+        Ws = [rs.randn(c, c_out) * 0.3 for c in cs]
+        z = sum(g @ w for g, w in zip(Gs, Ws))
+        ref = {"relu": np.maximum(z, 0), "tanh": np.tanh(z), "none": z, "leaky_relu": np.where(z >= 0, z, 0.01 * z)}[act]
+        dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+        out = ops.dense_terms_forward([dev(g) for g in Gs], [dev(w) for w in Ws], c_out, act)
+        assert _maxdiff(out.cpu().numpy(), ref) <= TOL
+        # backward: G'_k [.., c_k] are the transposed-shift terms of the upstream gradient, W_k [c_aux, c_k]
+        aux = rs.randn(S, R, ns, c_aux)
+        if act == "relu":
+            aux = np.maximum(aux, 0)
+        if act == "tanh":
+            aux = np.tanh(aux)
+        Wb = [rs.randn(c_aux, c) * 0.3 for c in cs]
+        dact = {"relu": (aux > 0) * 1.0, "tanh": 1 - aux ** 2, "none": np.ones_like(aux),
+                "leaky_relu": np.where(aux >= 0, 1.0, 0.01)}[act]
+        dx_ref = sum(g @ w.T for g, w in zip(Gs, Wb)) * dact
+        dW_ref = [np.einsum("srna,srnc->ac", aux, g) for g in Gs]
+        dWs = [torch.full((c_aux, c), 0.5, device="cuda") for c in cs]
+        dx = ops.dense_terms_backward([dev(g) for g in Gs], [dev(w) for w in Wb], dev(aux), act, True, dWs)
+        assert _maxdiff(dx.cpu().numpy(), dx_ref) <= TOL
+        for a, b in zip(dWs, dW_ref):
+            assert _maxdiff(a.cpu().numpy(), b + 0.5) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_rectangular_single_operator_spmm(cfg1, sc1):
+    """The LDS-blocked SpMM on the Bunch shifts (rectangular, one value array, no identity) and their transposes."""
+    from scone_gcn_amd import ops
+    rs = np.random.RandomState(1)
+    for sh in sc1.bunch_shifts():
+        for m in (sh.device_csr(), sh.device_csr().T.tocsr()):
+            op = ops.ConvOp(m.shape[0], [{"mats": [m], "identity": False, "n_cols": m.shape[1]}])
+            for k in (4, 64, 128):
+                x = rs.randn(2, m.shape[1], k).astype(np.float32)
+                y, _ = op.spmm_dual(torch.from_numpy(x).cuda(), dual=False)
+                for s in range(2):
+                    assert _maxdiff(y[s].cpu().numpy(), m @ x[s].astype(np.float64)) <= 2e-5
+
+
+def test_bunch_two_layers_larger_complex_against_csr_oracle():
+    """Bunch, two layers x hidden 16, on an E ~ 13k complex: blocked per-shift SpMM + dense kernels, node/face orders."""
+    _need_gpu()
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    cx = g.random_SC_graph(5000)
+    sc = SimplicialComplex(cx)
+    paths = g.generate_random_walks(cx, m=12, seed=5)
+    flows, choice, last, tnodes, _ = g.path_dataset(cx, paths, seed=2)
+    n = len(paths)
+    X = flows.todense()[:n].astype(np.float64)
+    last = np.asarray(last[:n])
+    nb, D = sc.nbrhoods, sc.max_degree
+    y = so.onehot_targets(choice[:n], D)
+    ynode = y                                # bunch targets use the same neighbour-slot one-hot layout
+    shapes = so.weight_shapes(1, [(7, 16), (7, 16)], 1, "bunch")
+    w = _rand_weights(shapes, 0.3, 5)
+    B1, B2 = g.incidence_matrices(cx)
+    S = [m.tocsr() for m in compute_shift_matrices(B1, B2)]
+    mask = np.ones(n, int)
+    ref_out = so.bunch_forward(w, S, nb, last, X)
+    ref_loss, ref_g = so.bunch_loss_and_grad(w, S, nb, last, X, ynode, mask, 0.0)
+    shifts, nbrhoods, _ = te.setup_from_complex(sc, "bunch")
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+    assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
+    loss = -(out * torch.as_tensor(ynode, dtype=torch.float32, device="cuda")).sum() / n
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL * max(1.0, np.abs(ref_g[k]).max()), "weight %d" % k
 
 
 def test_errors_are_loud(cfg1, sc1):

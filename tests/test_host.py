@@ -65,7 +65,7 @@ def test_layout_is_a_permutation_and_device_csr_is_conjugated(cx):
     for lvl in range(3):
         assert np.array_equal(np.sort(lay.order[lvl]), np.arange(lay.sizes[lvl]))
         assert np.array_equal(lay.perm[lvl][lay.order[lvl]], np.arange(lay.sizes[lvl]))
-    assert not lay.is_identity(1) and lay.is_identity(0)
+    assert not lay.is_identity(0) and not lay.is_identity(1) and not lay.is_identity(2)
     S = sc.scone_shifts()[0]
     D = S.device_csr().toarray()
     P = lay.perm[1]
