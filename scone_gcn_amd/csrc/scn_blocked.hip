@@ -1188,6 +1188,251 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward, c_dz = c_aux = 32 on the bf16 MFMA with the exact three-way split (default; see the note above fwd_c32_w16).
+// Same block / slab pipeline and lane roles as bwd_c32_kernel; what changes is the contraction (v_mfma_f32_32x32x16_bf16):
+//   dgrad      D[pt][ca]  = sum_{g,c} G_g[pt][c] W_g[ca][c]   A = split(G_g) in its gather layout (lane = point p, channels
+//                           16h+8t+j), B = split(W_g) fragments kept in LDS (18 KB, where the fp32 kernel has its patch)
+//   transpose  T_g[pt][c] = sum_k G_g[pt][k] I[k][c]           the same A fragments against a 0/1 selection matrix: the D
+//                           layout hands every lane 16 points of ONE channel (exact: hi+mid+lo re-add to the fp32 value),
+//                           which is the B operand the weight gradient needs -- no LDS round trip
+//   dW_g       D[ca][c]  += sum_pt aux[pt][ca] T_g[pt][c]      A = split(aux tile) straight from the dgrad D layout
+// 90 MFMAs x 32 cycles per 32-point tile instead of 96 x 64, and the splitting VALU work of one wave runs under the
+// partner wave's MFMAs.
+// ------------------------------------------------------------------------------------------------
+constexpr int B32_WFRAG_BYTES = 3 * 2 * 3 * 64 * 16;      // [segment][k-step][split][lane] x 8 bf16
+
+__global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, const float* __restrict__ DZ,
+                                                                     const float* __restrict__ W0,
+                                                                     const float* __restrict__ W1,
+                                                                     const float* __restrict__ W2,
+                                                                     const float* __restrict__ aux,
+                                                                     float* __restrict__ dx, float* __restrict__ partial,
+                                                                     int n_rows, int n_cols, int n_slabs, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
+    const Smem sm = carve(smem, PIECE);
+    char* wfrag = smem + smem_bytes(PIECE);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5, n = p & 3, rt = wave * 8 + (p >> 2);
+    STAMP_DECL;
+    // dgrad B fragments: (g, t, lane) holds W_g[ca = lane&31][c = 16*(lane>>5) + 8t + j], j = 0..7
+    for (int f = threadIdx.x; f < 3 * 2 * 64; f += BK_THREADS) {
+        const int g = f / 128, t = (f >> 6) & 1, l = f & 63;
+        const float* Wg = g == 0 ? W0 : (g == 1 ? W1 : W2);
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = Wg[(l & 31) * 32 + 16 * (l >> 5) + 8 * t + j];
+        const Split3 sp = split3(w);
+        char* base = wfrag + ((g * 2 + t) * 3) * 1024 + l * 16;
+        *(bf16x8*)(base) = sp.hi;
+        *(bf16x8*)(base + 1024) = sp.mid;
+        *(bf16x8*)(base + 2048) = sp.lo;
+    }
+    // selection fragments: k-step t, B[k = 8h + j][n = p] = (p == 16h + 8t + j)
+    bf16x8 Isel[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c0 = 16 * h + 8 * t + 2 * i;
+            v[i] = (p == c0 ? 0x3F80u : 0u) | (p == c0 + 1 ? 0x3F800000u : 0u);
+        }
+        Isel[t] = __builtin_bit_cast(bf16x8, v);
+    }
+    f32x16 dWacc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWacc[g][r] = 0.f;
+    int b, b_end, b_stride;
+    block_range(P.n_blocks, b, b_end, b_stride);
+    SCN_SLAB_RANGE();
+    int cq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cq[q] = (n * 8 + h * 4 + q) ^ (n >> 1);
+    const size_t slab_bytes = (size_t)n_cols * PIECE;
+    if (slab0 < slab1)
+    for (; b < b_end; b += b_stride) {
+        wait_all_and_barrier();
+        const BlockMeta m = load_block(P, b, sm);
+        __syncthreads();
+        const int tw = P.tile_w[b * BK_WAVES + wave];
+        const int rtc = rt < m.rows ? rt : m.rows - 1;
+        uint32_t goff[NDMA];
+        const int total = m.nsrc * CPP;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int c = (i * BK_WAVES + wave) * 64 + lane;
+            const int slot = c / CPP, pos = c % CPP;
+            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * PIECE + swz32(slot, pos) * 16 : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int base = (i * BK_WAVES + wave) * 64;
+            if (base + lane < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)DZ + (size_t)slab0 * slab_bytes + goff[i]),
+                                                 (__attribute__((address_space(3))) void*)(sm.buf(0) + base * 16), 16, 0, 0);
+        }
+        const int rows_left = m.rows - wave * 8;
+        for (int slab = slab0; slab < slab1; ++slab) {
+            const char* cur = sm.buf((slab - slab0) & 1);
+            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * 32;
+            const float* ap = aux + (rows_left > 0 ? tuni : 0);
+            float* dp = dx ? dx + tuni : nullptr;
+            const int L0 = p + 128 * h;
+            STAMP_START();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP_ADD(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP_ADD(1);
+            f32x4 G[3][4];
+            {
+                const int slot = sm.self[rtc];
+                const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
+                const char* base = cur + slot * PIECE;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    G[0][q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
+                    G[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    G[2][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const int rb = rtc * m.w;
+                EllPair en = ell_load(sm, rb);
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair e = en;
+                    if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
+                    const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
+                    const int x1 = (((e.s1 >> 1) & 1) << 2) | ((e.s1 & 1) << 1);
+                    const char* b0 = cur + e.s0 * PIECE;
+                    const char* b1 = cur + e.s1 * PIECE;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 d0 = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+                        G[1][q] += e.v[0] * d0;
+                        G[2][q] += e.v[1] * d0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 d1 = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
+                        G[1][q] += e.v[2] * d1;
+                        G[2][q] += e.v[3] * d1;
+                    }
+                }
+            }
+            STAMP_ADD(2);
+            // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; four vector-memory side operations per group
+            // (8 LDS-DMA of the next slab, then the tile's 16 aux values)
+            float a[16];
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 T[3];
+            const bool more = slab + 1 < slab1;
+            const char* Xn = (const char*)DZ + (size_t)(slab + 1) * slab_bytes;
+            char* nbuf = sm.buf((slab + 1 - slab0) & 1);
+            auto side = [&](int k) {
+                if (k < NDMA) {
+                    const int base = (k * BK_WAVES + wave) * 64;
+                    if (more && base + lane < total)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
+                                                         (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
+                } else {
+                    const int r = k - NDMA;
+                    const bool ok = 2 * (r >> 2) + h < rows_left;
+                    const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * 32 : 0];
+                    a[r] = ok ? v : 0.f;
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[g][r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float x8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x8[j] = G[g][2 * t + (j >> 2)][j & 3];
+                    const Split3 zs = split3(x8);
+                    const char* wb = wfrag + ((g * 2 + t) * 3) * 1024 + lane * 16;
+                    const bf16x8 wh = *(const bf16x8*)(wb), wm = *(const bf16x8*)(wb + 1024), wl = *(const bf16x8*)(wb + 2048);
+                    const int k0 = (g * 2 + t) * 4;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, wh, acc, 0, 0, 0);
+                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, Isel[t], T[g], 0, 0, 0);
+                    side(k0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wl, acc, 0, 0, 0);
+                    side(k0 + 1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wm, acc, 0, 0, 0);
+                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, Isel[t], T[g], 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wh, acc, 0, 0, 0);
+                    side(k0 + 2);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wm, acc, 0, 0, 0);
+                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, Isel[t], T[g], 0, 0, 0);
+                    side(k0 + 3);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wh, acc, 0, 0, 0);
+                }
+            }
+            STAMP_ADD(3);
+            // dW A fragments from the aux tile (k-step t <-> points pt(8t + j, h)), then dX = acc * act'(aux)
+            Split3 At[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float x8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x8[j] = a[8 * t + j];
+                At[t] = split3(x8);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(act, a[r]);
+            // dW_g += aux^T T_g; the 16 dx stores ride inside the chains
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float x8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x8[j] = T[g][8 * t + j];
+                    const Split3 bs = split3(x8);
+                    const Split3& at = At[t];
+                    const int k0 = (g * 2 + t) * 3;                       // 18 store slots, 16 used
+                    auto store = [&](int r) {
+                        if (dp && r < 16 && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+                    };
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bs.hi, dWacc[g], 0, 0, 0);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.lo, dWacc[g], 0, 0, 0);
+                    store(k0);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bs.mid, dWacc[g], 0, 0, 0);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bs.hi, dWacc[g], 0, 0, 0);
+                    store(k0 + 1);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.mid, dWacc[g], 0, 0, 0);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.hi, dWacc[g], 0, 0, 0);
+                    store(k0 + 2);
+                }
+            }
+            STAMP_ADD(4);
+        }
+    }
+    STAMP_FLUSH();
+    wait_all_and_barrier();
+    float* red = (float*)sm.buf(0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ca = (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[wave * 3072 + ca * 96 + g * 32 + p] = dWacc[g][r];
+        }
+    __syncthreads();
+    float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
+    for (int i = threadIdx.x; i < 3072; i += BK_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) s += red[w * 3072 + i];
+        outp[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward, c_dz = c_aux = 16  (16x16x4 MFMA, two 16-point tiles per wave)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const float* __restrict__ DZ,
@@ -1568,9 +1813,16 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     const size_t lds = bwd_lds(cd, c_aux);
     launch_grid(c, n_slabs, lds, grid);
     if (c_aux == 32) {
-        SCN_ENSURE_LDS(bwd_c32_kernel, lds);
-        hipLaunchKernelGGL(bwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
-                           nc, n_slabs, act);
+        static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
+        if (f32_mfma) {
+            SCN_ENSURE_LDS(bwd_c32_kernel, lds);
+            hipLaunchKernelGGL(bwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial,
+                               nr, nc, n_slabs, act);
+        } else {
+            SCN_ENSURE_LDS(bwd_c32_bf16_kernel, lds);
+            hipLaunchKernelGGL(bwd_c32_bf16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx,
+                               partial, nr, nc, n_slabs, act);
+        }
     } else if (c_aux == 16) {
         SCN_ENSURE_LDS(bwd_c16_kernel, lds);
         hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
