@@ -221,6 +221,59 @@ __device__ __forceinline__ int swz32(int slot, int chunk) {
 }
 __device__ __forceinline__ int swz16(int slot, int chunk) { return chunk ^ (slot & 3); }
 
+// Gather of one lane's NQ 16-byte chunks of row `row` from the staged 512-byte pieces: identity term gs, and the ELL row
+// (entry pairs) accumulated into gl (val0 operator) and gu (val1 operator).  All 2*NQ LDS reads of an entry pair are issued
+// before the first FMA and the next pair's slots / values are fetched (raw) behind them: left to itself hipcc serialises
+// read -> s_waitcnt lgkmcnt(0) -> use under register pressure, which exposed ~10 LDS latencies per entry pair.
+template <int NQ>
+__device__ __forceinline__ void gather_c32(const Smem& sm, const char* cur, int row, int w, int tw, const int (&cq)[NQ],
+                                           f32x4 (&gs)[NQ], f32x4 (&gl)[NQ], f32x4 (&gu)[NQ]) {
+    constexpr int PIECE = 512;
+    const int rb = row * w;
+    uint32_t ss = *(const uint16_t*)(sm.slot + rb);
+    f32x4 v = *(const f32x4*)(sm.v + rb);
+    {
+        const int slot = sm.self[row];
+        const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
+        const char* base = cur + slot * PIECE;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            gs[q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
+            gl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (int t = 0; t < tw; t += 2) {
+        const int s0 = ss & 255, s1 = ss >> 8;
+        const f32x4 vc = v;
+        const int x0 = (((s0 >> 1) & 1) << 2) | ((s0 & 1) << 1);
+        const int x1 = (((s1 >> 1) & 1) << 2) | ((s1 & 1) << 1);
+        const char* b0 = cur + s0 * PIECE;
+        const char* b1 = cur + s1 * PIECE;
+        f32x4 d0[NQ], d1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d0[q] = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d1[q] = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
+        if (t + 2 < tw) {
+            ss = *(const uint16_t*)(sm.slot + rb + t + 2);
+            v = *(const f32x4*)(sm.v + rb + t + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            gl[q] += vc[0] * d0[q];
+            gu[q] += vc[1] * d0[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            gl[q] += vc[2] * d1[q];
+            gu[q] += vc[3] * d1[q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LDS-DMA of nsrc pieces of slab-base Xs into buf: LDS image is lane-linear, the swizzle goes on the SOURCE chunk.
 template <int PIECE, int SWZ>
 __device__ __forceinline__ void dma_stage(const char* Xs, char* buf, const Smem& sm, int nsrc) {
@@ -1196,18 +1249,20 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
 //                           layout hands every lane 16 points of ONE channel (exact: hi+mid+lo re-add to the fp32 value),
 //                           which is the B operand the weight gradient needs -- no LDS round trip
 //   dW_g       D[ca][c]  += sum_pt aux[pt][ca] T_g[pt][c]      A = split(aux tile) straight from the dgrad D layout
-// 90 MFMAs x 32 cycles per 32-point tile instead of 96 x 64, and the splitting VALU work of one wave runs under the
-// partner wave's MFMAs.
+// 90 MFMAs x 32 cycles per 32-point tile instead of 96 x 64.  MFMA and VALU time add up on a SIMD (tools/ubench), so
+// the VALU instruction count (5.5 per split value) matters as much as the MFMA count.
 // ------------------------------------------------------------------------------------------------
 constexpr int B32_WFRAG_BYTES = 3 * 2 * 3 * 64 * 16;      // [segment][k-step][split][lane] x 8 bf16
+static_assert(B32_WFRAG_BYTES <= BK_WAVES * 16 * T32_STRIDE * 4, "weight fragments take the place of the fp32 kernel's patches");
 
+template <int ACT>
 __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, const float* __restrict__ DZ,
                                                                      const float* __restrict__ W0,
                                                                      const float* __restrict__ W1,
                                                                      const float* __restrict__ W2,
                                                                      const float* __restrict__ aux,
                                                                      float* __restrict__ dx, float* __restrict__ partial,
-                                                                     int n_rows, int n_cols, int n_slabs, int act) {
+                                                                     int n_rows, int n_cols, int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
     const Smem sm = carve(smem, PIECE);
@@ -1246,6 +1301,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dWacc[g][r] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
     SCN_SLAB_RANGE();
@@ -1288,45 +1344,26 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             STAMP_ADD(1);
-            f32x4 G[3][4];
-            {
-                const int slot = sm.self[rtc];
-                const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
-                const char* base = cur + slot * PIECE;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    G[0][q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
-                    G[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    G[2][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                const int rb = rtc * m.w;
-                EllPair en = ell_load(sm, rb);
-                for (int t = 0; t < tw; t += 2) {
-                    const EllPair e = en;
-                    if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
-                    const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
-                    const int x1 = (((e.s1 >> 1) & 1) << 2) | ((e.s1 & 1) << 1);
-                    const char* b0 = cur + e.s0 * PIECE;
-                    const char* b1 = cur + e.s1 * PIECE;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 d0 = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
-                        G[1][q] += e.v[0] * d0;
-                        G[2][q] += e.v[1] * d0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 d1 = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
-                        G[1][q] += e.v[2] * d1;
-                        G[2][q] += e.v[3] * d1;
-                    }
-                }
-            }
-            STAMP_ADD(2);
-            // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; four vector-memory side operations per group
-            // (8 LDS-DMA of the next slab, then the tile's 16 aux values)
+            // the tile's 16 aux values and the first weight fragments are requested before the gather so that their
+            // latency (HBM / LDS) is covered by it; they are issued ahead of the next slab's LDS-DMA, so waiting for them
+            // later leaves the DMA in flight
             float a[16];
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = 2 * (r >> 2) + h < rows_left;
+                const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * 32 : 0];
+                a[r] = ok ? v : 0.f;
+            }
+            bf16x8 wn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wfrag + lane * 16 + i * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 G[3][4];
+            gather_c32<4>(sm, cur, rtc, m.w, tw, cq, G[0], G[1], G[2]);
+            STAMP_ADD(2);
+            // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; the 8 LDS-DMA instructions of the next slab ride in
+            // the first four groups
+            f32x16 acc = zero16;
             f32x16 T[3];
             const bool more = slab + 1 < slab1;
             const char* Xn = (const char*)DZ + (size_t)(slab + 1) * slab_bytes;
@@ -1337,38 +1374,34 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     if (more && base + lane < total)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
                                                          (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
-                } else {
-                    const int r = k - NDMA;
-                    const bool ok = 2 * (r >> 2) + h < rows_left;
-                    const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * 32 : 0];
-                    a[r] = ok ? v : 0.f;
                 }
             };
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[g][r] = 0.f;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float x8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x8[j] = G[g][2 * t + (j >> 2)][j & 3];
                     const Split3 zs = split3(x8);
-                    const char* wb = wfrag + ((g * 2 + t) * 3) * 1024 + lane * 16;
-                    const bf16x8 wh = *(const bf16x8*)(wb), wm = *(const bf16x8*)(wb + 1024), wl = *(const bf16x8*)(wb + 2048);
-                    const int k0 = (g * 2 + t) * 4;
+                    const bf16x8 wh = wn[0], wm = wn[1], wl = wn[2];
+                    const int k0 = (g * 2 + t) * 2;                          // two LDS-DMA side slots per group (8 used)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, wh, acc, 0, 0, 0);
-                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, Isel[t], T[g], 0, 0, 0);
+                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, Isel[t], t == 0 ? zero16 : T[g], 0, 0, 0);
+                    if (g * 2 + t < 5) {                                     // next group's fragments, one group ahead
+                        const char* wb = wfrag + ((g * 2 + t + 1) * 3) * 1024 + lane * 16;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wb + i * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     side(k0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wl, acc, 0, 0, 0);
                     side(k0 + 1);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wm, acc, 0, 0, 0);
                     T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, Isel[t], T[g], 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wh, acc, 0, 0, 0);
-                    side(k0 + 2);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wm, acc, 0, 0, 0);
                     T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, Isel[t], T[g], 0, 0, 0);
-                    side(k0 + 3);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wh, acc, 0, 0, 0);
                 }
             }
@@ -1383,7 +1416,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                 At[t] = split3(x8);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(act, a[r]);
+            for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(ACT, a[r]);
             // dW_g += aux^T T_g; the 16 dx stores ride inside the chains
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -1819,9 +1852,18 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
             hipLaunchKernelGGL(bwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial,
                                nr, nc, n_slabs, act);
         } else {
-            SCN_ENSURE_LDS(bwd_c32_bf16_kernel, lds);
-            hipLaunchKernelGGL(bwd_c32_bf16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx,
-                               partial, nr, nc, n_slabs, act);
+#define SCN_LAUNCH_BWD32(A)                                                                                       \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS(bwd_c32_bf16_kernel<A>, lds);                                                              \
+        hipLaunchKernelGGL(bwd_c32_bf16_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, \
+                           partial, nr, nc, n_slabs);                                                             \
+    } while (0)
+            switch (act) {
+                case SCN_ACT_TANH: SCN_LAUNCH_BWD32(SCN_ACT_TANH); break;
+                case SCN_ACT_RELU: SCN_LAUNCH_BWD32(SCN_ACT_RELU); break;
+                case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWD32(SCN_ACT_LEAKY_RELU); break;
+                default: SCN_LAUNCH_BWD32(SCN_ACT_NONE); break;
+            }
         }
     } else if (c_aux == 16) {
         SCN_ENSURE_LDS(bwd_c16_kernel, lds);

@@ -14,7 +14,8 @@ E, C, S = cx.n_edges, 32, 32
 W = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
 x = torch.randn(S, E, 4, C, device="cuda")
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-os.environ["SCN_F32_MFMA"] = "1"       # the stamps live in the fp32-MFMA forward kernel
+if which == "fwd" or "f32" in sys.argv:
+    os.environ["SCN_F32_MFMA"] = "1"   # forward stamps live in the fp32-MFMA kernel; backward: bf16 kernel unless "f32" is given
 def run():
     if which == "fwd":
         plan.conv.forward([x], W, C, "tanh")
