@@ -148,6 +148,9 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, width, &P.dev.width)) != SCN_OK) return st;
     if ((st = upload(c, tile_w, &P.dev.tile_w)) != SCN_OK) return st;
     if ((st = upload(c, ell_slot, &P.dev.ell_slot)) != SCN_OK) return st;
+    std::vector<uint16_t> ell_enc(ell_slot.size());
+    for (size_t i = 0; i < ell_slot.size(); ++i) ell_enc[i] = (uint16_t)((ell_slot[i] << 9) | ((ell_slot[i] & 3) << 5));   // slot*512 | slot part of swz32
+    if ((st = upload(c, ell_enc, &P.dev.ell_enc)) != SCN_OK) return st;
     if ((st = upload(c, ell_v, &P.dev.ell_v)) != SCN_OK) return st;
     if ((st = upload(c, self_slot, &P.dev.self_slot)) != SCN_OK) return st;
     P.mean_src_per_row = (double)total_src / std::max(1, n_rows);
@@ -221,42 +224,83 @@ __device__ __forceinline__ int swz32(int slot, int chunk) {
 }
 __device__ __forceinline__ int swz16(int slot, int chunk) { return chunk ^ (slot & 3); }
 
+// ---- C = 32 (512-byte pieces): LDS carve with 16-bit pre-encoded ELL slots, and the gather built on it ----
+// [buf0][buf1][ell_v: BK_ELL_CAP float2][srcrows: BK_SRC i32][enc: BK_ELL_CAP u16][self: BK_R u8][extra]
+struct SmemC32 {
+    char* buf0;
+    __device__ __forceinline__ char* buf(int i) const { return buf0 + i * (BK_SRC * 512); }
+    float2* v;
+    int32_t* srcrows;
+    uint16_t* enc;
+    uint8_t* self;
+};
+__host__ __device__ static inline size_t smem_bytes_c32(int extra = 0) {
+    size_t b = (size_t)2 * BK_SRC * 512 + (size_t)BK_ELL_CAP * 10 + BK_SRC * 4 + BK_R;
+    return ((b + 15) / 16) * 16 + extra;
+}
+__device__ __forceinline__ SmemC32 carve_c32(char* base) {
+    SmemC32 s;
+    s.buf0 = base;
+    s.v = (float2*)(base + 2 * BK_SRC * 512);
+    s.srcrows = (int32_t*)(s.v + BK_ELL_CAP);
+    s.enc = (uint16_t*)(s.srcrows + BK_SRC);
+    s.self = (uint8_t*)(s.enc + BK_ELL_CAP);
+    return s;
+}
+static_assert(BK_SRC * 512 == 65536 && BK_SRC <= 128, "gather_c32 XORs slot*512 (< 2^16) with the buffer bit 2^16");
+
+template <int NT>
+__device__ __forceinline__ BlockMeta load_block_c32(const PlanDev& P, int b, const SmemC32& sm) {
+    BlockMeta m;
+    m.row0 = P.blk_row0[b];
+    m.rows = P.blk_rows[b];
+    const int sp0 = P.src_ptr[b];
+    m.nsrc = P.src_ptr[b + 1] - sp0;
+    m.w = P.width[b];
+    const int ep = P.ell_ptr[b];
+    for (int i = threadIdx.x; i < m.nsrc; i += NT) sm.srcrows[i] = P.src_rows[sp0 + i];
+    for (int i = threadIdx.x; i < m.w * m.rows; i += NT) {
+        sm.enc[i] = P.ell_enc[ep + i];
+        sm.v[i] = P.ell_v[ep + i];
+    }
+    if (threadIdx.x < BK_R) sm.self[threadIdx.x] = P.self_slot[(size_t)b * BK_R + threadIdx.x];
+    return m;
+}
+
 // Gather of one lane's NQ 16-byte chunks of row `row` from the staged 512-byte pieces: identity term gs, and the ELL row
-// (entry pairs) accumulated into gl (val0 operator) and gu (val1 operator).  All 2*NQ LDS reads of an entry pair are issued
-// before the first FMA and the next pair's slots / values are fetched (raw) behind them: left to itself hipcc serialises
-// read -> s_waitcnt lgkmcnt(0) -> use under register pressure, which exposed ~10 LDS latencies per entry pair.
+// (entry pairs) accumulated into gl (val0 operator) and gu (val1 operator).
+//  * cb[q] = (this lane's swizzled chunk index << 4) | (buffer index << 16); the LDS address of a chunk is cb[q] ^ enc with
+//    enc = slot*512 | (slot&3)*32 straight from the plan: one v_xor per read instead of five address instructions -- these
+//    kernels are VALU-issue bound (profiles/r01_pmc_fwd_bwd_c32_bf16.txt), so instruction count is what matters;
+//  * all 2*NQ LDS reads of an entry pair are issued before the first FMA and the next pair's slots / values are fetched
+//    behind them: left to itself hipcc serialises read -> s_waitcnt lgkmcnt(0) -> use under register pressure.
 template <int NQ>
-__device__ __forceinline__ void gather_c32(const Smem& sm, const char* cur, int row, int w, int tw, const int (&cq)[NQ],
+__device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, const uint32_t (&cb)[NQ],
                                            f32x4 (&gs)[NQ], f32x4 (&gl)[NQ], f32x4 (&gu)[NQ]) {
-    constexpr int PIECE = 512;
-    const int rb = row * w;
-    uint32_t ss = *(const uint16_t*)(sm.slot + rb);
+    const char* lds = sm.buf0;
+    const int rb = row * w;                                   // w is even: entry pairs are 4-byte aligned
+    uint32_t ss = *(const uint32_t*)(sm.enc + rb);
     f32x4 v = *(const f32x4*)(sm.v + rb);
     {
-        const int slot = sm.self[row];
-        const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
-        const char* base = cur + slot * PIECE;
+        const uint32_t slot = sm.self[row];
+        const uint32_t enc = (slot << 9) | ((slot & 3) << 5);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            gs[q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
+            gs[q] = *(const f32x4*)(lds + (cb[q] ^ enc));
             gl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     for (int t = 0; t < tw; t += 2) {
-        const int s0 = ss & 255, s1 = ss >> 8;
+        const uint32_t e0 = ss & 0xffffu, e1 = ss >> 16;
         const f32x4 vc = v;
-        const int x0 = (((s0 >> 1) & 1) << 2) | ((s0 & 1) << 1);
-        const int x1 = (((s1 >> 1) & 1) << 2) | ((s1 & 1) << 1);
-        const char* b0 = cur + s0 * PIECE;
-        const char* b1 = cur + s1 * PIECE;
         f32x4 d0[NQ], d1[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) d0[q] = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
+        for (int q = 0; q < NQ; ++q) d0[q] = *(const f32x4*)(lds + (cb[q] ^ e0));
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) d1[q] = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
+        for (int q = 0; q < NQ; ++q) d1[q] = *(const f32x4*)(lds + (cb[q] ^ e1));
         if (t + 2 < tw) {
-            ss = *(const uint16_t*)(sm.slot + rb + t + 2);
+            ss = *(const uint32_t*)(sm.enc + rb + t + 2);
             v = *(const f32x4*)(sm.v + rb + t + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -708,12 +752,13 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                                                                      int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / W16_THREADS;   // 4 LDS-DMA instructions per wave
-    const Smem sm = carve(smem, PIECE);
-    char* wfrag = smem + smem_bytes(PIECE);
+    const SmemC32 sm = carve_c32(smem);
+    char* wfrag = smem + smem_bytes_c32();
     uint8_t* tws = (uint8_t*)(wfrag + W16_WFRAG_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = lane & 15, kq = lane >> 4, n = pt & 3, rt = wave * 4 + (pt >> 2);
+    STAMP_DECL;
     // split the weights once: fragment (g, ct, split, lane) = W_g[8*kq' + j][16*ct + i], i = lane&15, kq' = lane>>4
     for (int f = tid; f < 3 * 2 * 64; f += W16_THREADS) {
         const int g = f / 128, ct = (f >> 6) & 1, l = f & 63;
@@ -735,9 +780,9 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
     float* pend_ptr = nullptr;
     bool pend_valid = false;
     // chunk index of this lane's two 16-byte chunks inside a piece: n*8 + kq*2 + q, swizzled like the 8-wave kernels
-    int cq[2];
+    uint32_t cqs[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) cq[q] = (n * 8 + kq * 2 + q) ^ (n >> 1);
+    for (int q = 0; q < 2; ++q) cqs[q] = (uint32_t)((n * 8 + kq * 2 + q) ^ (n >> 1)) << 4;
     const size_t slab_bytes = (size_t)n_cols * PIECE;
     for (; b < b_end; b += b_stride) {
         wait_all_and_barrier();
@@ -751,7 +796,7 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
             const int ep = P.ell_ptr[b];
             for (int i = tid; i < m.nsrc; i += W16_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
             for (int i = tid; i < m.w * m.rows; i += W16_THREADS) {
-                sm.slot[i] = P.ell_slot[ep + i];
+                sm.enc[i] = P.ell_enc[ep + i];
                 sm.v[i] = P.ell_v[ep + i];
             }
             if (tid < BK_R) sm.self[tid] = P.self_slot[(size_t)b * BK_R + tid];
@@ -777,46 +822,21 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) dma(i, (const char*)X + (size_t)slab0 * slab_bytes, sm.buf(0));
         for (int slab = slab0; slab < slab1; ++slab) {
-            const char* cur = sm.buf((slab - slab0) & 1);
-            wait_vm_and_barrier();
+            STAMP_START();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP_ADD(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP_ADD(1);
             const bool more = slab + 1 < slab1;
             const char* Xn = (const char*)X + (size_t)(slab + 1) * slab_bytes;
             char* nbuf = sm.buf((slab + 1 - slab0) & 1);
             f32x4 z[3][2];                 // [segment][chunk q]: channels 8*kq + 4*q .. +3 of this lane's point
             {
-                const int slot = sm.self[rtc];
-                const int sx = (((slot >> 1) & 1) << 2) | ((slot & 1) << 1);
-                const char* base = cur + slot * PIECE;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    z[0][q] = *(const f32x4*)(base + ((cq[q] ^ sx) << 4));
-                    z[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    z[2][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                const int rb = rtc * m.w;
-                EllPair en = ell_load(sm, rb);
-                for (int t = 0; t < tw; t += 2) {
-                    const EllPair e = en;
-                    if (t + 2 < tw) en = ell_load(sm, rb + t + 2);
-                    const int x0 = (((e.s0 >> 1) & 1) << 2) | ((e.s0 & 1) << 1);
-                    const int x1 = (((e.s1 >> 1) & 1) << 2) | ((e.s1 & 1) << 1);
-                    const char* b0 = cur + e.s0 * PIECE;
-                    const char* b1 = cur + e.s1 * PIECE;
-                    f32x4 d0[2], d1[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        d0[q] = *(const f32x4*)(b0 + ((cq[q] ^ x0) << 4));
-                        d1[q] = *(const f32x4*)(b1 + ((cq[q] ^ x1) << 4));
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        z[1][q] += e.v[0] * d0[q];
-                        z[2][q] += e.v[1] * d0[q];
-                        z[1][q] += e.v[2] * d1[q];
-                        z[2][q] += e.v[3] * d1[q];
-                    }
-                }
+                const uint32_t cb[2] = {cqs[0] | (uint32_t)(((slab - slab0) & 1) << 16), cqs[1] | (uint32_t)(((slab - slab0) & 1) << 16)};
+                gather_c32<2>(sm, rtc, m.w, tw, cb, z[0], z[1], z[2]);
             }
+            STAMP_ADD(2);
             // MFMA: out^T tile (16 channels x 16 points) x 2 channel tiles; LDS-DMA of the next slab and the previous tile's
             // two 16-byte stores ride inside the chains
             {
@@ -856,8 +876,10 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
             // D: column = lane&15 = point, row = 4*kq + r = channel within the 16-channel tile
             pend_ptr = out + (((size_t)slab * n_rows + m.row0 + rt) * BK_NS + n) * 32 + 4 * kq;
             pend_valid = rt < m.rows;
+            STAMP_ADD(3);
         }
     }
+    STAMP_FLUSH();
     if (pend_ptr && pend_valid) {
         *(f32x4*)(pend_ptr) = pend[0];
         *(f32x4*)(pend_ptr + 16) = pend[1];
@@ -1265,8 +1287,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                                                      int n_rows, int n_cols, int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
-    const Smem sm = carve(smem, PIECE);
-    char* wfrag = smem + smem_bytes(PIECE);
+    const SmemC32 sm = carve_c32(smem);
+    char* wfrag = smem + smem_bytes_c32();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 31, h = lane >> 5, n = p & 3, rt = wave * 8 + (p >> 2);
@@ -1305,14 +1327,14 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
     int b, b_end, b_stride;
     block_range(P.n_blocks, b, b_end, b_stride);
     SCN_SLAB_RANGE();
-    int cq[4];
+    uint32_t cqs[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cq[q] = (n * 8 + h * 4 + q) ^ (n >> 1);
+    for (int q = 0; q < 4; ++q) cqs[q] = (uint32_t)((n * 8 + h * 4 + q) ^ (n >> 1)) << 4;
     const size_t slab_bytes = (size_t)n_cols * PIECE;
     if (slab0 < slab1)
     for (; b < b_end; b += b_stride) {
         wait_all_and_barrier();
-        const BlockMeta m = load_block(P, b, sm);
+        const BlockMeta m = load_block_c32<BK_THREADS>(P, b, sm);
         __syncthreads();
         const int tw = P.tile_w[b * BK_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
@@ -1333,7 +1355,6 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         }
         const int rows_left = m.rows - wave * 8;
         for (int slab = slab0; slab < slab1; ++slab) {
-            const char* cur = sm.buf((slab - slab0) & 1);
             const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * 32;
             const float* ap = aux + (rows_left > 0 ? tuni : 0);
             float* dp = dx ? dx + tuni : nullptr;
@@ -1359,7 +1380,11 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wfrag + lane * 16 + i * 1024);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 G[3][4];
-            gather_c32<4>(sm, cur, rtc, m.w, tw, cq, G[0], G[1], G[2]);
+            {
+                const uint32_t bufbit = (uint32_t)(((slab - slab0) & 1) << 16);
+                const uint32_t cb[4] = {cqs[0] | bufbit, cqs[1] | bufbit, cqs[2] | bufbit, cqs[3] | bufbit};
+                gather_c32<4>(sm, rtc, m.w, tw, cb, G[0], G[1], G[2]);
+            }
             STAMP_ADD(2);
             // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; the 8 LDS-DMA instructions of the next slab ride in
             // the first four groups
@@ -1772,7 +1797,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
                        n_slabs)
         static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
         if (!f32_mfma) {                                                   // default: the 16-wave bf16x3 kernel
-            const size_t lds16 = smem_bytes(512, W16_WFRAG_BYTES + 16);
+            const size_t lds16 = smem_bytes_c32(W16_WFRAG_BYTES + 16);
 #define SCN_LAUNCH_FWD32W(A)                                                                                      \
     do {                                                                                                          \
         SCN_ENSURE_LDS(fwd_c32_w16_kernel<A>, lds16);                                                             \
@@ -1822,7 +1847,7 @@ bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz
 }
 
 static size_t bwd_lds(int cd, int c_aux) {
-    if (c_aux == 32) return smem_bytes(512, BK_WAVES * 16 * T32_STRIDE * 4);
+    if (c_aux == 32) return smem_bytes_c32(B32_WFRAG_BYTES);   // (>= the fp32 variant's smem_bytes(512) + patches)
     if (c_aux == 16) return smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4);
     return smem_bytes(BK_NS * cd * 4, 16);
 }

@@ -96,6 +96,7 @@ struct PlanDev {
     const uint8_t* width;       // [n_blocks] padded entries per row
     const uint8_t* tile_w;      // [n_blocks][BK_WAVES] entries needed by each wave's 8 rows
     const uint8_t* ell_slot;    // local slot of entry
+    const uint16_t* ell_enc;    // the same for 512-byte pieces, ready to XOR into an LDS address: slot*512 | (slot&3)*32
     const float2* ell_v;        // (val0, val1) of entry
     const uint8_t* self_slot;   // [n_blocks][BK_R] slot of the row itself (identity shift)
 };

@@ -24,6 +24,7 @@ shifts, readout, _ = te.setup_from_complex(sc, "scone")
 plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
 print("plan blocks, sources/row:", plan.conv.plan_info(), flush=True)
 E, C, S = cx.n_edges, a.hidden, a.slabs
+torch.manual_seed(0)
 dev = "cuda"
 W = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
 W1 = [torch.randn(1, C, device=dev) * 0.1 for _ in range(3)]
@@ -43,6 +44,12 @@ def one_pass():
         plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
 
 
+if "fwd" in which:              # checksums: A/B builds of a kernel must agree on these
+    print("checksum fwd %.9e" % float(plan.conv.forward([x], W, C, "tanh").double().abs().sum()), flush=True)
+if "bwd" in which:
+    dWs = [torch.zeros_like(w) for w in W]
+    dxx = plan.conv.backward([x], W, x, "tanh", True, dWs)
+    print("checksum bwd %.9e %.9e" % (float(dxx.double().abs().sum()), float(sum(d.double().abs().sum() for d in dWs))), flush=True)
 one_pass()                      # untimed warm-up (first launches set function attributes, fault in pages)
 torch.cuda.synchronize()
 with ops.KernelTimer() as kt:
