@@ -78,6 +78,10 @@ typedef struct {
 } scn_group_desc;
 
 int scn_conv_create(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups, scn_conv_t* out);
+/* Same, with a layout hint: block_start[r] != 0 (host, n_rows bytes, or NULL) forces a block of the LDS-blocked plan to
+ * begin at row r (the plan may still cut more often).  Produced by scn_plan_refine_order for the row order it returns. */
+int scn_conv_create_blocked(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups,
+                            const uint8_t* block_start, scn_conv_t* out);
 int scn_conv_destroy(scn_conv_t conv);
 int scn_conv_n_slots(scn_conv_t conv);
 /* rows per LDS-staged block and mean staged source rows per block of the blocked plan (0 if none) */
@@ -170,6 +174,14 @@ int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
 int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_entries,
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
+
+/* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
+ * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)
+ * returns order[new] = old that sorts the rows of every block the plan would cut by descending entry count, so the
+ * 8-row groups a wave walks in lock-step are padded less, and block_start[new] = 1 where those blocks begin.
+ * identity != 0: the operator also reads the row itself. */
+int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t identity, int32_t* order,
+                          uint8_t* block_start);
 
 /* Fused Adam + ridge step on the flat parameter buffer (jax.experimental.optimizers.adam as driven by
  * STM:300-326; ridge term of STM:54-56):   g' = g * g_scale + 2*weight_decay*w ; m,v EMA ;

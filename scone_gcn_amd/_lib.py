@@ -30,6 +30,7 @@ SIGNATURES = {
     "scn_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "scn_last_hip_error": (ctypes.c_char_p, []),
     "scn_conv_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(GroupDesc), ctypes.POINTER(c_void_p)]),
+    "scn_conv_create_blocked": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(GroupDesc), c_void_p, ctypes.POINTER(c_void_p)]),
     "scn_conv_destroy": (ctypes.c_int, [c_void_p]),
     "scn_conv_n_slots": (ctypes.c_int, [c_void_p]),
     "scn_conv_plan_info": (ctypes.c_int, [c_void_p, P_i32, P_f32]),
@@ -58,6 +59,7 @@ SIGNATURES = {
                                                  c_void_p, c_i32, c_void_p, c_void_p]),
     "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
+    "scn_plan_refine_order": (ctypes.c_int, [c_i32, P_i32, P_i32, c_i32, P_i32, c_void_p]),
     "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_void_p]),
 }

@@ -49,13 +49,34 @@ def _hilbert_order(pts):
     return np.argsort(hilbert_index(q[:, 0], q[:, 1]), kind="stable")
 
 
-class Layout:
-    """Row permutation of the three levels: perm[level][old] = new, order[level][new] = old."""
+def _refine_order(pattern, order):
+    """(order[new] = old, block_start[new]) with rows re-sorted by entry count inside the device plan's blocks
+    (scn_plan_refine_order; host-side code of the library, no GPU involved)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    m = sp.csr_matrix(pattern)[order][:, order].tocsr()
+    m.sort_indices()
+    n = m.shape[0]
+    rowptr = np.ascontiguousarray(m.indptr, np.int32)
+    col = np.ascontiguousarray(m.indices, np.int32)
+    out = np.empty(n, np.int32)
+    starts = np.zeros(n, np.uint8)
+    as_p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    _lib.check(lib.scn_plan_refine_order(n, as_p(rowptr), as_p(col), 1, as_p(out), starts.ctypes.data),
+               "scn_plan_refine_order")
+    return np.asarray(order)[out], starts
 
-    def __init__(self, sizes, orders=None):
+
+class Layout:
+    """Row permutation of the three levels: perm[level][old] = new, order[level][new] = old; block_starts[level] is the
+    optional cut hint for the LDS-blocked plan (1 where a block begins) that goes with the order."""
+
+    def __init__(self, sizes, orders=None, block_starts=None):
         self.sizes = tuple(int(s) for s in sizes)
         self.order = []
         self.perm = []
+        self.block_starts = list(block_starts) if block_starts is not None else [None, None, None]
         for lvl, n in enumerate(self.sizes):
             o = np.arange(n, dtype=np.int64) if orders is None or orders[lvl] is None else np.asarray(orders[lvl], np.int64)
             assert len(o) == n and np.array_equal(np.sort(o), np.arange(n))
@@ -200,7 +221,15 @@ class SimplicialComplex:
                 orders[1] = rcm(self.B1.T @ self.B1)
                 if cx.n_faces > 1:
                     orders[2] = rcm(self.B2.T @ self.B2)
-        self.layout = Layout((cx.n_nodes, cx.n_edges, cx.n_faces), orders)
+        starts = [None, None, None]
+        if reorder and cx.n_edges > 1:
+            # second pass: inside the 64-row blocks of the device plan, sort rows by the entry count of the level's own
+            # Laplacian (the lanes of a wave walk their rows' ELL lists in lock-step; see scn_plan_refine_order)
+            pats = [self.B1 @ self.B1.T, self.B1.T @ self.B1, self.B2.T @ self.B2 if cx.n_faces > 1 else None]
+            for lvl in range(3):
+                if orders[lvl] is not None and pats[lvl] is not None:
+                    orders[lvl], starts[lvl] = _refine_order(pats[lvl], orders[lvl])
+        self.layout = Layout((cx.n_nodes, cx.n_edges, cx.n_faces), orders, starts)
 
     @classmethod
     def from_incidence(cls, B1, B2, coords=None, reorder=True):

@@ -63,6 +63,34 @@ static int upload(scn_conv_s* c, const std::vector<T>& h, const T** out) {
     return SCN_OK;
 }
 
+// Greedy block cut shared by the plan builder and scn_plan_refine_order: starting at row r0, take consecutive rows (< r_end)
+// while the block stays within BK_R rows, BK_SRC distinct source rows (the rows themselves included when the operator has
+// an identity slot) and BK_ELL_CAP padded ELL entries.  `mark` is a per-column stamp array (block id), `cur` gets the sources.
+static void grow_block(const int32_t* rowptr, const int32_t* col, int r_end, bool has_id, int r0, int bid,
+                       std::vector<int32_t>& mark, std::vector<int32_t>& cur, int& rows, int& w) {
+    cur.clear();
+    rows = 0;
+    w = 0;
+    while (r0 + rows < r_end && rows < BK_R) {
+        const int r = r0 + rows;
+        const int j0 = rowptr[r], j1 = rowptr[r + 1];
+        int add = 0;
+        for (int j = j0; j < j1; ++j)
+            if (mark[col[j]] != bid) ++add;
+        bool self_new = has_id && mark[r] != bid;
+        for (int j = j0; j < j1 && self_new; ++j)
+            if (col[j] == r) self_new = false;
+        if (self_new) ++add;
+        const int nw = std::max(w, (j1 - j0 + 1) & ~1);          // padded width, even
+        if ((int)cur.size() + add > BK_SRC || nw * (rows + 1) > BK_ELL_CAP || nw > 254) break;
+        for (int j = j0; j < j1; ++j)
+            if (mark[col[j]] != bid) { mark[col[j]] = bid; cur.push_back(col[j]); }
+        if (has_id && mark[r] != bid) { mark[r] = bid; cur.push_back(r); }
+        w = nw;
+        ++rows;
+    }
+}
+
 int build_block_plan(scn_conv_s* c) {
     // only the scone/ebli shape gets a plan; everything else runs the generic kernels
     // single-group operators get a plan: identity + 2 value arrays is the scone/ebli layer (MFMA kernels); one value
@@ -80,27 +108,13 @@ int build_block_plan(scn_conv_s* c) {
     int64_t total_src = 0;
     int wmax = 0;
     int bid = 0;
+    const uint8_t* hint = c->block_start.empty() ? nullptr : c->block_start.data();
     for (int r0 = 0; r0 < n_rows;) {
-        cur.clear();
-        int rows = 0, w = 0;
-        while (r0 + rows < n_rows && rows < BK_R) {
-            const int r = r0 + rows;
-            const int j0 = G.h_rowptr[r], j1 = G.h_rowptr[r + 1];
-            int add = 0;
-            for (int j = j0; j < j1; ++j)
-                if (mark[G.h_col[j]] != bid) ++add;
-            bool self_new = has_id && mark[r] != bid;
-            for (int j = j0; j < j1 && self_new; ++j)
-                if (G.h_col[j] == r) self_new = false;
-            if (self_new) ++add;
-            const int nw = std::max(w, (j1 - j0 + 1) & ~1);          // padded width, even
-            if ((int)cur.size() + add > BK_SRC || nw * (rows + 1) > BK_ELL_CAP || nw > 254) break;
-            for (int j = j0; j < j1; ++j)
-                if (mark[G.h_col[j]] != bid) { mark[G.h_col[j]] = bid; cur.push_back(G.h_col[j]); }
-            if (has_id && mark[r] != bid) { mark[r] = bid; cur.push_back(r); }
-            w = nw;
-            ++rows;
-        }
+        int rows = 0, w = 0, r_limit = n_rows;
+        if (hint)                                               // a hinted boundary closes the block (limits still apply)
+            for (int r = r0 + 1; r < std::min(n_rows, r0 + BK_R + 1); ++r)
+                if (hint[r]) { r_limit = r; break; }
+        grow_block(G.h_rowptr.data(), G.h_col.data(), r_limit, has_id, r0, bid, mark, cur, rows, w);
         if (rows == 0) return SCN_OK;   // a single row does not fit: no plan (generic kernels will be used)
         std::sort(cur.begin(), cur.end());
         for (size_t i = 0; i < cur.size(); ++i) local[cur[i]] = (int32_t)i;
@@ -1931,6 +1945,36 @@ int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, f
 }
 
 }  // namespace scn
+
+
+// Host-only layout helper (no reference counterpart: the reference's dense operators have no storage order).
+// All lanes of a wave walk the ELL rows of their 8-row group to the group's widest row, so a block whose rows are sorted
+// by entry count wastes fewer gather iterations (1.25x -> 1.09x of nnz at |E| = 1M).  For a SQUARE pattern whose rows and
+// columns share one index space: order[new] = old (rows only move inside the blocks the plan would cut) and
+// block_start[new] = 1 where those blocks begin -- pass it to scn_conv_create_blocked so the plan keeps exactly these cuts.
+extern "C" int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t identity, int32_t* order,
+                                     uint8_t* block_start) {
+    if (n < 0 || !rowptr || !order || !block_start || (n > 0 && !col && rowptr[n] > 0)) return SCN_ERR_BAD_ARG;
+    for (int64_t j = 0; j < rowptr[n]; ++j)
+        if (col[j] < 0 || col[j] >= n) return SCN_ERR_BAD_SHAPE;
+    std::vector<int32_t> mark(n, -1), cur;
+    cur.reserve(scn::BK_SRC + 64);
+    int bid = 0;
+    for (int r0 = 0; r0 < n; ++bid) {
+        int rows = 0, w = 0;
+        scn::grow_block(rowptr, col, n, identity != 0, r0, bid, mark, cur, rows, w);
+        if (rows == 0) rows = 1;                                  // a row the plan cannot hold: leave it where it is
+        for (int i = 0; i < rows; ++i) {
+            order[r0 + i] = r0 + i;
+            block_start[r0 + i] = i == 0;
+        }
+        std::stable_sort(order + r0, order + r0 + rows, [&](int32_t a, int32_t b) {
+            return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b];
+        });
+        r0 += rows;
+    }
+    return SCN_OK;
+}
 
 #ifdef SCN_STAMPS
 extern "C" int scn_debug_stamps(unsigned long long* out8, int reset) {

@@ -289,12 +289,18 @@ int scn_conv_destroy(scn_conv_t c) {
 }
 
 int scn_conv_create(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups, scn_conv_t* out) {
+    return scn_conv_create_blocked(n_rows, n_groups, groups, nullptr, out);
+}
+
+int scn_conv_create_blocked(int32_t n_rows, int32_t n_groups, const scn_group_desc* groups, const uint8_t* block_start,
+                            scn_conv_t* out) {
     if (!out || !groups || n_rows <= 0 || n_groups <= 0 || n_groups > SCN_MAX_GROUPS) return SCN_ERR_BAD_ARG;
     *out = nullptr;
     scn_conv_s* c = new (std::nothrow) scn_conv_s();
     if (!c) return SCN_ERR_NOMEM;
     c->n_rows = n_rows;
     c->n_groups = n_groups;
+    if (block_start) c->block_start.assign(block_start, block_start + n_rows);
     int slot = 0;
     for (int g = 0; g < n_groups; ++g) {
         const scn_group_desc& d = groups[g];

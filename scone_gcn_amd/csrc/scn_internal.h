@@ -116,4 +116,5 @@ struct scn_conv_s {
     int32_t slot_group[SCN_MAX_SLOTS] = {0, 0, 0, 0};
     int32_t slot_kind[SCN_MAX_SLOTS] = {0, 0, 0, 0};   // 0 identity, 1 val0, 2 val1
     scn::BlockPlan plan;
+    std::vector<uint8_t> block_start;   // optional layout hint: 1 where a block of the plan must start (see scn_plan_refine_order)
 };

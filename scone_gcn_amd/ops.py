@@ -67,7 +67,7 @@ class ConvOp:
     """One shift-convolution operator (scn_conv_t).  groups: list of dicts
     {"mats": [scipy csr in DEVICE order] (0..2, same shape), "identity": bool, "n_cols": int}."""
 
-    def __init__(self, n_rows, groups):
+    def __init__(self, n_rows, groups, block_start=None):
         lib = _lib.load()
         self.n_rows = int(n_rows)
         self.group_cols = []
@@ -94,7 +94,13 @@ class ConvOp:
             self.group_cols.append(n_cols)
             self.slot_group += [gi] * (d.identity + d.n_vals)
         h = ctypes.c_void_p()
-        check(lib.scn_conv_create(self.n_rows, len(groups), descs, ctypes.byref(h)), "scn_conv_create")
+        if block_start is not None:                # layout hint that goes with the row order (Layout.block_starts)
+            block_start = np.ascontiguousarray(block_start, np.uint8)
+            assert len(block_start) == self.n_rows
+            keep.append(block_start)
+        check(lib.scn_conv_create_blocked(self.n_rows, len(groups), descs,
+                                          block_start.ctypes.data if block_start is not None else None, ctypes.byref(h)),
+              "scn_conv_create")
         self.handle = h
         self.n_groups = len(groups)
         self.n_slots = len(self.slot_group)
@@ -272,11 +278,12 @@ class SconePlan:
         E = S_lower.shape[0]
         self.n_edges = E
         lo, up = S_lower.device_csr(), S_upper.device_csr()
-        self.conv = ConvOp(E, [{"mats": [lo, up], "identity": True, "n_cols": E}])
+        hint = self.layout.block_starts[S_lower.row_level]
+        self.conv = ConvOp(E, [{"mats": [lo, up], "identity": True, "n_cols": E}], hint)
         if S_lower.is_symmetric() and S_upper.is_symmetric():
             self.conv_T = self.conv
         else:
-            self.conv_T = ConvOp(E, [{"mats": [lo.T.tocsr(), up.T.tocsr()], "identity": True, "n_cols": E}])
+            self.conv_T = ConvOp(E, [{"mats": [lo.T.tocsr(), up.T.tocsr()], "identity": True, "n_cols": E}], hint)
         self.nnz_pattern = self.conv.nnz[0]
         self.nnz_lower, self.nnz_upper = int(lo.nnz), int(up.nnz)
         ptr, edge, sign, edge_nodes = bconds.incidence_tables()
@@ -372,10 +379,13 @@ class BunchPlan:
         self.device = device
         self.sizes = self.layout.sizes
         dev = [s.device_csr() for s in shifts]
+        hints = self.layout.block_starts
         self.term_fwd = [ConvOp(self.sizes[BUNCH_DST[k]], [{"mats": [dev[k]], "identity": False,
-                                                           "n_cols": self.sizes[BUNCH_SRC[k]]}]) for k in range(7)]
+                                                           "n_cols": self.sizes[BUNCH_SRC[k]]}], hints[BUNCH_DST[k]])
+                         for k in range(7)]
         self.term_bwd = [ConvOp(self.sizes[BUNCH_SRC[k]], [{"mats": [dev[k].T.tocsr()], "identity": False,
-                                                           "n_cols": self.sizes[BUNCH_DST[k]]}]) for k in range(7)]
+                                                           "n_cols": self.sizes[BUNCH_DST[k]]}], hints[BUNCH_SRC[k]])
+                         for k in range(7)]
         self.fwd_slots = [[k for k in range(7) if BUNCH_DST[k] == lvl] for lvl in range(3)]
         self.bwd_slots = [[k for k in range(7) if BUNCH_SRC[k] == lvl] for lvl in range(3)]
         self._dev_csr = dev

@@ -70,12 +70,20 @@ def test_layout_is_a_permutation_and_device_csr_is_conjugated(cx):
     D = S.device_csr().toarray()
     P = lay.perm[1]
     assert np.array_equal(D[np.ix_(P, P)], S.toarray())       # D = P S P^T
-    # locality: a 64-row block of the reordered operator needs far fewer distinct source rows than the input order
-    def ratio(M):
+    # locality: a block of the reordered operator (the layout's own cut points) needs far fewer distinct source rows per
+    # row than 64-row windows of the input order; inside a block the rows are sorted by entry count
+    def ratio(M, starts):
         M = sp.csr_matrix(M)
-        return np.mean([len(np.unique(M.indices[M.indptr[r]:M.indptr[min(r + 64, M.shape[0])]])) / 64
-                        for r in range(0, M.shape[0] - 64, 64)])
-    assert ratio(S.device_csr()) < 0.75 * ratio(S.csr)
+        b = np.flatnonzero(starts) if starts is not None else np.arange(0, M.shape[0], 64)
+        e = np.append(b[1:], M.shape[0])
+        return np.mean([len(np.unique(M.indices[M.indptr[i]:M.indptr[j]])) / (j - i) for i, j in zip(b, e)])
+    starts = lay.block_starts[1]
+    assert starts is not None and starts[0] == 1 and np.diff(np.flatnonzero(starts)).max() <= 64
+    assert ratio(S.device_csr(), starts) < 0.8 * ratio(S.csr, None)
+    nnz = np.diff(S.device_csr().indptr)
+    b = np.flatnonzero(starts)
+    for i, j in zip(b, np.append(b[1:], len(nnz))):
+        assert np.all(np.diff(nnz[i:j]) <= 0)
     # no coordinates -> reverse Cuthill-McKee fallback still yields a valid layout
     sc2 = SimplicialComplex(g.Complex(cx.n_nodes, cx.edges, cx.faces, None, cx.valid_idxs))
     assert np.array_equal(np.sort(sc2.layout.order[1]), np.arange(cx.n_edges))
