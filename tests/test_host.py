@@ -80,10 +80,14 @@ def test_layout_is_a_permutation_and_device_csr_is_conjugated(cx):
     starts = lay.block_starts[1]
     assert starts is not None and starts[0] == 1 and np.diff(np.flatnonzero(starts)).max() <= 64
     assert ratio(S.device_csr(), starts) < 0.8 * ratio(S.csr, None)
-    nnz = np.diff(S.device_csr().indptr)
-    b = np.flatnonzero(starts)
-    for i, j in zip(b, np.append(b[1:], len(nnz))):
-        assert np.all(np.diff(nnz[i:j]) <= 0)
+    def padded(nnz, b):      # lane-entries the 8-row groups walk, relative to the stored entries
+        tot = 0
+        for i, j in zip(b, np.append(b[1:], len(nnz))):
+            for k in range(i, j, 8):
+                tot += ((nnz[k:min(k + 8, j)].max() + 1) & ~1) * 8
+        return tot / nnz.sum()
+    nat = np.diff(S.csr.indptr)
+    assert padded(np.diff(S.device_csr().indptr), np.flatnonzero(starts)) < 0.92 * padded(nat, np.arange(0, len(nat), 64))
     # no coordinates -> reverse Cuthill-McKee fallback still yields a valid layout
     sc2 = SimplicialComplex(g.Complex(cx.n_nodes, cx.edges, cx.faces, None, cx.valid_idxs))
     assert np.array_equal(np.sort(sc2.layout.order[1]), np.arange(cx.n_edges))
