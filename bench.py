@@ -153,6 +153,8 @@ def main():
             caux = int(key.split("->")[1].split()[0])
             wr = 0 if "dW only" in key else caux
             return 4.0 * E * mb * (cdz + caux + wr) + csr_bytes
+        if key.startswith("conv_dw_first"):                      # same tensors as the dW-only backward: dz and x, once
+            return 4.0 * E * mb * (int(key.split("c")[2]) + 1) + csr_bytes
         return None
     tot = {k: n * ms for k, (n, ms) in ksum.items()}
     dom = max((k for k in tot if alg_bytes(k) is not None), key=lambda k: tot[k])
@@ -160,7 +162,7 @@ def main():
     achieved = alg_bytes(dom) / (ms * 1e-3)
     # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/; same |E|, hidden and launch size only)
     traffic = None
-    kmap = {"conv_bwd c32->32": "scn::bwd_c32_kernel", "conv_fwd c32->32": "scn::fwd_c32_kernel",
+    kmap = {"conv_bwd c32->32": "scn::bwd_c32_bf16_kernel", "conv_fwd c32->32": "scn::fwd_c32_w16_kernel",
             "conv_fwd c1->32": "scn::fwd_c1_kernel", "conv_bwd c32->1 (dW only)": "scn::bwd_c1_kernel"}
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tfile) and dom in kmap and E == 996634 and mb == 128:

@@ -175,6 +175,22 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
 
+/* First layer (c_in = 1) fast path.
+ * scn_conv_forward_first = scn_conv_forward for one 1-channel input, which also stores the shifted input
+ *   y[n_slabs][n_rows][ns][3] = (x, S_val0 x, S_val1 x)  -- the three scalars per point the kernel forms anyway.
+ * scn_conv_dw_first: weight gradient of that layer (no input gradient) with the shift on the 1-channel side,
+ *   dW_slot[0][c] += sum_p y[p][slot] * dz[p][c]   (= what jax.grad of TE:144-149 yields for weights[0:3], STM:307):
+ *   dz is read exactly once, coalesced.  Pass the y saved by the forward, or y = NULL and x: it is then recomputed into
+ *   the workspace.  `conv` is the FORWARD operator (identity + 2 value arrays) in both calls.
+ *   x   device [n_slabs][n_rows][ns][1]      dz  device [n_slabs][n_rows][ns][c_dz]     dW[3] device [1][c_dz], accumulated
+ * Both return SCN_ERR_UNSUPPORTED (workspace query: 0) when the operator has no blocked plan or the width is not 16 / 32;
+ * callers then use scn_conv_forward / scn_conv_backward. */
+int scn_conv_forward_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x, const float* const* W,
+                           int32_t c_out, int32_t act, float* out, float* y_out, void* stream);
+size_t scn_conv_dw_first_workspace(scn_conv_t conv, int32_t n_slabs, int32_t ns, int32_t c_dz);
+int scn_conv_dw_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x, const float* y, const float* dz,
+                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)
  * returns order[new] = old that sorts the rows of every block the plan would cut by descending entry count, so the

@@ -59,6 +59,11 @@ SIGNATURES = {
                                                  c_void_p, c_i32, c_void_p, c_void_p]),
     "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
+    "scn_conv_dw_first_workspace": (c_size_t, [c_void_p, c_i32, c_i32, c_i32]),
+    "scn_conv_dw_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32,
+                                         ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "scn_conv_forward_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_i32, c_i32,
+                                              c_void_p, c_void_p, c_void_p]),
     "scn_plan_refine_order": (ctypes.c_int, [c_i32, P_i32, P_i32, c_i32, P_i32, c_void_p]),
     "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_void_p]),

@@ -1016,8 +1016,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
                                                                const float* __restrict__ W0,
                                                                const float* __restrict__ W1,
                                                                const float* __restrict__ W2,
-                                                               float* __restrict__ out, int n_rows, int n_cols,
-                                                               int n_slabs, int act) {
+                                                               float* __restrict__ out, float* __restrict__ Yout,
+                                                               int n_rows, int n_cols, int n_slabs, int act) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 16, CQ = C / 4;
     const Smem sm = carve(smem, PIECE);
@@ -1057,6 +1057,10 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
                 Zs[tid * 3] = zs; Zs[tid * 3 + 1] = zl; Zs[tid * 3 + 2] = zu;
             }
             __syncthreads();   // Z visible (the DMA in flight is drained here too: acceptable for this light kernel)
+            if (Yout) {        // the shifted input (x, S_lo x, S_up x) per point, as scn_conv_dw_first takes it: Z verbatim
+                float* yb = Yout + ((size_t)slab * n_rows + m.row0) * (BK_NS * 3);
+                for (int i = tid; i < m.rows * 3; i += BK_THREADS) *(f32x4*)(yb + 4 * i) = *(const f32x4*)(Zs + 4 * i);
+            }
             float* o = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * C);
             const int total = m.rows * BK_NS * CQ;
             for (int idx = tid; idx < total; idx += BK_THREADS) {
@@ -1746,6 +1750,119 @@ __global__ __launch_bounds__(SP_THREADS, 4) void bwd_c1_kernel(PlanDev P, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// First-layer weight gradient with the shift moved to the cheap side (scn_conv_dw_first):
+//   dW_g[0][c] = sum_p (S_g x)[p] * dz[p][c]     instead of     sum_p x[p] * (S_g^T dz)[p][c]
+// gather3_c1_kernel computes Y[p] = (x, S_lo x, S_up x)[p] from the 16-byte input pieces (the gather of fwd_c1, 12 bytes per
+// point out); dw_first_stream_kernel then reads dz exactly once, coalesced, with no LDS gather at all -- an HBM stream.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BK_THREADS, 2) void gather3_c1_kernel(PlanDev P, const float* __restrict__ X,
+                                                                   float* __restrict__ Y, int n_rows, int n_cols,
+                                                                   int n_slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIECE = 16;
+    const Smem sm = carve(smem, PIECE);
+    const int tid = threadIdx.x;
+    int b, b_end, b_stride;
+    block_range(P.n_blocks, b, b_end, b_stride);
+    SCN_SLAB_RANGE();
+    if (slab0 >= slab1) return;
+    for (; b < b_end; b += b_stride) {
+        wait_all_and_barrier();
+        const BlockMeta m = load_block(P, b, sm);
+        __syncthreads();
+        dma_stage<PIECE, 0>((const char*)X + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        for (int slab = slab0; slab < slab1; ++slab) {
+            const float* st = (const float*)sm.buf((slab - slab0) & 1);
+            wait_vm_and_barrier();
+            if (slab + 1 < slab1)
+                dma_stage<PIECE, 0>((const char*)X + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                                    m.nsrc);
+            if (tid < m.rows * BK_NS) {
+                const int rt = tid >> 2, n = tid & 3;
+                float zs = st[sm.self[rt] * 4 + n], zl = 0.f, zu = 0.f;
+                const int tw = P.tile_w[b * BK_WAVES + (rt >> 3)];
+                const int rb = rt * m.w;
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair e = ell_load(sm, rb + t);
+                    const float d0 = st[e.s0 * 4 + n], d1 = st[e.s1 * 4 + n];
+                    zl = fmaf(e.v[0], d0, zl);
+                    zu = fmaf(e.v[1], d0, zu);
+                    zl = fmaf(e.v[2], d1, zl);
+                    zu = fmaf(e.v[3], d1, zu);
+                }
+                float* y = Y + (((size_t)slab * n_rows + m.row0) * BK_NS + tid) * 3;
+                y[0] = zs; y[1] = zl; y[2] = zu;
+            }
+        }
+    }
+}
+
+constexpr int DWS_THREADS = 256, DWS_BLOCKS = 1024;
+template <int C>
+__global__ __launch_bounds__(DWS_THREADS) void dw_first_stream_kernel(const float* __restrict__ Y,
+                                                                      const float* __restrict__ DZ,
+                                                                      float* __restrict__ partial, int64_t n_points) {
+    constexpr int CQ = C / 4;                                     // channel quads per point; DWS_THREADS % CQ == 0
+    __shared__ f32x4 red[3 * DWS_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t total = n_points * CQ, stride = (int64_t)gridDim.x * DWS_THREADS;
+    f32x4 acc[3];
+    acc[0] = acc[1] = acc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t i = (int64_t)blockIdx.x * DWS_THREADS + tid;
+    for (; i + 3 * stride < total; i += 4 * stride) {            // four independent 16-byte loads in flight per thread
+        f32x4 d[4];
+        float y[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * stride;
+            d[u] = *(const f32x4*)(DZ + j * 4);
+            const float* yp = Y + (j / CQ) * 3;
+            y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] += y[u][0] * d[u];
+            acc[1] += y[u][1] * d[u];
+            acc[2] += y[u][2] * d[u];
+        }
+    }
+    for (; i < total; i += stride) {
+        const f32x4 d = *(const f32x4*)(DZ + i * 4);
+        const float* yp = Y + (i / CQ) * 3;
+        acc[0] += yp[0] * d;
+        acc[1] += yp[1] * d;
+        acc[2] += yp[2] * d;
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) red[g * DWS_THREADS + tid] = acc[g];
+    __syncthreads();
+    if (tid < 3 * CQ) {                                           // threads with equal tid % CQ hold the same channels
+        const int g = tid / CQ, cq = tid - g * CQ;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = cq; t < DWS_THREADS; t += CQ) sum += red[g * DWS_THREADS + t];
+        float* outp = partial + (size_t)blockIdx.x * (3 * C) + g * C + cq * 4;
+        outp[0] = sum[0]; outp[1] = sum[1]; outp[2] = sum[2]; outp[3] = sum[3];
+    }
+}
+
+// dW_slot[0][cc] += sum over the stream kernel's partials: one wave per output element, lane l adds partials l, l+64, ...
+// and the 64 lane sums are folded in a fixed butterfly order (deterministic).
+__global__ __launch_bounds__(64) void dw_first_reduce_kernel(const float* __restrict__ partial, int n_partials, int c,
+                                                             float* __restrict__ dW0, float* __restrict__ dW1,
+                                                             float* __restrict__ dW2) {
+    const int o = blockIdx.x, lane = threadIdx.x;                 // o = slot * c + cc
+    float s = 0.f;
+    for (int b = lane; b < n_partials; b += 64) s += partial[(size_t)b * (3 * c) + o];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) {
+        const int slot = o / c, cc = o - slot * c;
+        float* d = slot == 0 ? dW0 : (slot == 1 ? dW1 : dW2);
+        d[cc] += s;
+    }
+}
+
 // dW_slot[i] += sum over partials (fixed order).  layout: partial[b][ca*3c + slot*c + cc]
 __global__ void blocked_dw_reduce(const float* __restrict__ partial, int n_partials, int c_aux, int c,
                                   float* __restrict__ dW0, float* __restrict__ dW1, float* __restrict__ dW2) {
@@ -1794,7 +1911,7 @@ bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in,
 }
 
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
-                    const float* const* W, int c_out, int act, float* out, hipStream_t st) {
+                    const float* const* W, int c_out, int act, float* out, float* y_out, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
     dim3 grid;
     const int ci = c_in[0];
@@ -1843,11 +1960,11 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
         const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
         launch_grid(c, n_slabs, lds, grid);
         if (c_out == 32)
-            hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
-                               n_slabs, act);
+            hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
+                               nc, n_slabs, act);
         else
-            hipLaunchKernelGGL(fwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
-                               n_slabs, act);
+            hipLaunchKernelGGL(fwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
+                               nc, n_slabs, act);
     }
     SCN_LAUNCH_CHECK();
     return SCN_OK;
@@ -1919,6 +2036,45 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     const int per = c_aux * 3 * cd;
     hipLaunchKernelGGL(blocked_dw_reduce, dim3((per + 255) / 256), dim3(256), 0, st, partial, (int)(grid.x * grid.y), c_aux,
                        cd, dW[0], dW[1], dW[2]);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd) {
+    return scone_shape(c) && ns == BK_NS && (cd == 16 || cd == 32);
+}
+
+static size_t dw_first_y_bytes(const scn_conv_s* c, int n_slabs) {
+    const size_t b = (size_t)n_slabs * c->n_rows * BK_NS * 3 * sizeof(float);
+    return (b + 255) / 256 * 256;
+}
+
+size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd) {
+    if (!blocked_dw_first_supported(c, ns, cd)) return 0;
+    return dw_first_y_bytes(c, n_slabs) + (size_t)DWS_BLOCKS * 3 * cd * sizeof(float);
+}
+
+// y != nullptr: the shifted input saved by the forward (scn_conv_forward_first); otherwise it is computed here into ws
+int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd, float* const* dW,
+                     void* ws, hipStream_t st) {
+    const PlanDev& P = c->plan.dev;
+    float* partial = (float*)((char*)ws + dw_first_y_bytes(c, n_slabs));
+    if (!y) {
+        float* Y = (float*)ws;
+        dim3 grid;
+        const size_t lds = smem_bytes(16);
+        launch_grid(c, n_slabs, lds, grid);
+        hipLaunchKernelGGL(gather3_c1_kernel, grid, dim3(BK_THREADS), lds, st, P, x, Y, c->n_rows, c->g[0].n_cols, n_slabs);
+        SCN_LAUNCH_CHECK();
+        y = Y;
+    }
+    const int64_t n_points = (int64_t)n_slabs * c->n_rows * BK_NS;
+    if (cd == 32)
+        hipLaunchKernelGGL(dw_first_stream_kernel<32>, dim3(DWS_BLOCKS), dim3(DWS_THREADS), 0, st, y, dz, partial, n_points);
+    else
+        hipLaunchKernelGGL(dw_first_stream_kernel<16>, dim3(DWS_BLOCKS), dim3(DWS_THREADS), 0, st, y, dz, partial, n_points);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(3 * cd), dim3(64), 0, st, partial, DWS_BLOCKS, cd, dW[0], dW[1], dW[2]);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

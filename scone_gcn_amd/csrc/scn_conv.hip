@@ -19,13 +19,17 @@ int build_block_plan(scn_conv_s* c);
 void free_block_plan(scn_conv_s* c);
 bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in, int c_out);
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
-                    const float* const* W, int c_out, int act, float* out, hipStream_t st);
+                    const float* const* W, int c_out, int act, float* out, float* y_out, hipStream_t st);
 bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz, int c_aux, bool has_dx);
 size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux);
 int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
                      float* const* dW, void* ws, size_t ws_bytes, hipStream_t st);
 bool blocked_spmm_supported(const scn_conv_s* c, int k);
+bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
+size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
+int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
+                     float* const* dW, void* ws, hipStream_t st);
 int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
@@ -374,7 +378,7 @@ int scn_conv_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* con
         if (!W[s]) return SCN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (blocked_forward_supported(c, ns, c_in, c_out))
-        return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, st);
+        return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, st);
     FwdArgs a;
     std::memset(&a, 0, sizeof(a));
     fill_op(c, a.op);
@@ -404,6 +408,29 @@ size_t scn_conv_backward_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, co
     size_t generic = (size_t)generic_bwd_blocks(c, n_slabs) * cols * c_aux * sizeof(float);
     size_t blocked = blocked_backward_workspace(c, n_slabs, ns, c_dz, c_aux);
     return std::max(generic, blocked) + 256;
+}
+
+size_t scn_conv_dw_first_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, int32_t c_dz) {
+    if (!c || n_slabs <= 0) return 0;
+    return blocked_dw_first_workspace(c, n_slabs, ns, c_dz);
+}
+
+int scn_conv_dw_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x, const float* y, const float* dz,
+                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || (!x && !y) || !dz || !dW || !dW[0] || !dW[1] || !dW[2] || !workspace) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0) return SCN_ERR_BAD_SHAPE;
+    if (!blocked_dw_first_supported(c, ns, c_dz)) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < blocked_dw_first_workspace(c, n_slabs, ns, c_dz)) return SCN_ERR_WORKSPACE;
+    return blocked_dw_first(c, n_slabs, x, y, dz, c_dz, dW, workspace, (hipStream_t)stream);
+}
+
+int scn_conv_forward_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x, const float* const* W, int32_t c_out,
+                           int32_t act, float* out, float* y_out, void* stream) {
+    if (!c || !x || !W || !W[0] || !W[1] || !W[2] || !out || !y_out) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    const int32_t c_in = 1;
+    if (c->n_groups != 1 || c->n_slots != 3 || !blocked_forward_supported(c, ns, &c_in, c_out)) return SCN_ERR_UNSUPPORTED;
+    return blocked_forward(c, n_slabs, ns, &x, &c_in, W, c_out, act, out, y_out, (hipStream_t)stream);
 }
 
 int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,

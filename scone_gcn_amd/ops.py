@@ -162,6 +162,40 @@ class ConvOp:
                   "scn_conv_backward")
         return dx
 
+    def forward_first(self, x, Ws, c_out, act):
+        """First layer (one 1-channel input): returns (out, y) with y = (x, S_lo x, S_up x) per point, or None when the
+        shape is not served (scn_conv_forward_first)."""
+        lib = _lib.load()
+        S, rows, ns, c_in = x.shape
+        if c_in != 1 or self.n_groups != 1 or self.n_slots != 3:
+            return None
+        out = torch.empty((S, self.n_rows, ns, c_out), device=x.device, dtype=torch.float32)
+        y = torch.empty((S, self.n_rows, ns, 3), device=x.device, dtype=torch.float32)
+        with _timed("conv_fwd c1->%d" % c_out):
+            st = lib.scn_conv_forward_first(self.handle, S, ns, _dev(x), ptr_array([_dev(w).value for w in Ws]), c_out,
+                                            ACT[act], _dev(out), _dev(y), _stream())
+        if st == -4:                                   # SCN_ERR_UNSUPPORTED
+            return None
+        check(st, "scn_conv_forward_first")
+        return out, y
+
+    def dw_first(self, x, y, dz, dWs):
+        """First-layer weight gradient through the forward operator (scn_conv_dw_first); y: the shifted input saved by
+        forward_first (or None: recomputed from x).  False if the shape is not served."""
+        lib = _lib.load()
+        S, rows, ns, c = dz.shape
+        assert rows == self.n_rows and (y is None or tuple(y.shape) == (S, rows, ns, 3))
+        nbytes = int(lib.scn_conv_dw_first_workspace(self.handle, S, ns, c))
+        if nbytes == 0:
+            return False
+        ws = torch.empty(nbytes, device=dz.device, dtype=torch.uint8)
+        with _timed("conv_dw_first c%d" % c):
+            check(lib.scn_conv_dw_first(self.handle, S, ns, _dev(x) if x is not None else None,
+                                        _dev(y) if y is not None else None, _dev(dz), c,
+                                        ptr_array([_dev(d).value for d in dWs]), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                        _stream()), "scn_conv_dw_first")
+        return True
+
     def spmm_dual(self, x, dual=True):
         lib = _lib.load()
         S, rows, k = x.shape
@@ -296,11 +330,16 @@ class SconePlan:
     def conv_stack(self, x, weights):
         n_layers = (len(weights) - 1) / 3
         assert n_layers % 1 == 0, "wrong number of weights"                    # TE:141-142
-        hs = [x]
+        hs, y0 = [x], None
         for i in range(int(n_layers)):
             w = weights[3 * i:3 * i + 3]
-            hs.append(self.conv.forward([hs[-1]], w, w[0].shape[1], self.act))
-        return hs
+            first = self.conv.forward_first(x, w, w[0].shape[1], self.act) if i == 0 else None
+            if first is not None:                       # 1-channel input: keep the shifted input for the weight gradient
+                hs.append(first[0])
+                y0 = first[1]
+            else:
+                hs.append(self.conv.forward([hs[-1]], w, w[0].shape[1], self.act))
+        return hs, y0
 
     def readout(self, H, w_last, last_dev):
         lib = _lib.load()
@@ -317,14 +356,14 @@ class SconePlan:
         return logp, bh, logits
 
     def forward(self, x, last_dev, weights):
-        hs = self.conv_stack(x, weights)
+        hs, y0 = self.conv_stack(x, weights)
         logp, bh, _ = self.readout(hs[-1], weights[-1], last_dev)
-        return logp, (hs, bh)
+        return logp, (hs, bh, y0)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         """grads: list of tensors (same shapes as weights) accumulated into."""
         lib = _lib.load()
-        hs, bh = saved
+        hs, bh, y0 = saved
         H = hs[-1]
         S, E, ns, C = H.shape
         dz = torch.empty_like(H)
@@ -338,6 +377,8 @@ class SconePlan:
                                        _dev(grads[-1]), _stream()), "scn_readout_backward")
         L = len(hs) - 1
         for i in reversed(range(L)):
+            if i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3]):
+                break                                   # first layer: shifted 1-channel input x one stream over dz
             dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
         return grads
 

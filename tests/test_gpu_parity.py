@@ -346,6 +346,36 @@ def test_bunch_two_layers_larger_complex_against_csr_oracle():
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL * max(1.0, np.abs(ref_g[k]).max()), "weight %d" % k
 
 
+@pytest.mark.parametrize("hidden", [16, 32])
+def test_first_layer_fast_path_matches_generic_entry_points(cfg1, sc1, hidden):
+    """scn_conv_forward_first / scn_conv_dw_first (shift on the 1-channel side) against scn_conv_forward / scn_conv_backward
+    and against scipy for the shifted input."""
+    from scone_gcn_amd import ops
+    shifts = sc1.scone_shifts()
+    plan = ops.get_scone_plan(shifts[0], shifts[1], sc1.bconds(), "tanh", ops.default_device())
+    rs = np.random.RandomState(4)
+    S, E, C = 3, cfg1["E"], hidden
+    x = torch.from_numpy(rs.randn(S, E, 4, 1).astype(np.float32)).cuda()
+    dz = torch.from_numpy(rs.randn(S, E, 4, C).astype(np.float32)).cuda()
+    W = [torch.from_numpy((0.3 * rs.randn(1, C)).astype(np.float32)).cuda() for _ in range(3)]
+    out_ref = plan.conv.forward([x], W, C, "tanh")
+    out, y = plan.conv.forward_first(x, W, C, "tanh")
+    assert torch.equal(out, out_ref)
+    lo, up = shifts[0].device_csr(), shifts[1].device_csr()
+    xs = x.cpu().numpy().astype(np.float64)[..., 0]                    # (S, E, 4)
+    for s in range(S):
+        ref = np.stack([xs[s], lo @ xs[s], up @ xs[s]], axis=-1)       # (E, 4, 3)
+        assert _maxdiff(y[s].cpu().numpy(), ref) <= 2e-5
+    g_ref = [torch.zeros_like(w) for w in W]
+    plan.conv_T.backward([dz], W, x, "tanh", False, g_ref)
+    for yy in (None, y):
+        g = [torch.full_like(w, 0.25) for w in W]                      # accumulated into
+        assert plan.conv.dw_first(x, yy, dz, g)
+        for a, b in zip(g, g_ref):
+            bb = b.cpu().numpy().astype(np.float64)
+            assert _maxdiff(a.cpu().numpy(), bb + 0.25) <= 2e-5 * max(1.0, np.abs(bb).max())
+
+
 def test_errors_are_loud(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     shifts, readout, _ = te.setup_from_complex(sc1, "scone")

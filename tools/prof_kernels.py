@@ -42,6 +42,8 @@ def one_pass():
         plan.conv.backward([x], W, x, "tanh", True, [torch.zeros_like(w) for w in W])
     if "bwd1" in which:
         plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
+    if "dwf" in which:
+        assert plan.conv.dw_first(x1, None, x, [torch.zeros_like(w) for w in W1])
 
 
 if "fwd" in which:              # checksums: A/B builds of a kernel must agree on these
