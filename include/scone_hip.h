@@ -149,7 +149,7 @@ int scn_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
 
 /* Backward of the readout + log-softmax, fused with the last layer's activation derivative:
  *   d_logits = d_logp - exp(logp) * sum_d d_logp
- *   dz[e,n,:] = (sum_v sign(v,e) d_logits[n,d(v)]) * w_last * act'(H[e,n,:])    (dz fully written, zeros elsewhere)
+ *   dz[e,n,:] = (sum_v sign(v,e) d_logits[n,d(v)]) * w_last * act'(H[e,n,:])    (zeros elsewhere)
  *   d_w_last += sum_n sum_d d_logits[n,d] * bh[n,d,:]          (fixed summation order)               */
 int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
                          const float* H, const float* w_last,
@@ -158,7 +158,16 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
                          const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
                          const int32_t* edge_nodes, /* [n_edges][2] endpoints (tail, head) */
                          const float* bh, const float* d_logp, const float* logp, int32_t act,
-                         float* d_logits /* [N][max_deg] out */, float* dz, float* d_w_last, void* stream);
+                         float* d_logits /* [N][max_deg] out */, float* dz,
+                         int32_t dz_is_zero /* != 0: caller guarantees dz is all zeros (skips the memset of the dense tensor) */,
+                         float* d_w_last, void* stream);
+
+/* Writes zeros to exactly the dz entries scn_readout_backward fills for these last_nodes, so a buffer handed in with
+ * dz_is_zero = 1 is all-zero again once the layer above has consumed it (a few hundred rows instead of a full memset). */
+int scn_readout_clear_dz(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
+                         const int32_t* nbr, int32_t n_nodes, int32_t max_deg, const int32_t* last_nodes,
+                         const int32_t* inc_ptr, const int32_t* inc_edge, const int32_t* edge_nodes,
+                         float* dz, void* stream);
 
 /* Bunch readout (TE:198-203): logits[n,d] = nodes_out[nbr[last[n]][d]] with -1 wrapping to the last node. */
 int scn_node_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_nodes,

@@ -52,7 +52,9 @@ SIGNATURES = {
                                            c_void_p]),
     "scn_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                            c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
+    "scn_readout_clear_dz": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     "scn_node_readout_forward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
                                                 c_void_p, c_void_p]),
     "scn_node_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,

@@ -70,18 +70,21 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, in
                                                          const int32_t* __restrict__ edge_nodes,
                                                          const float* __restrict__ d_logp,
                                                          const float* __restrict__ logp, int act,
-                                                         float* __restrict__ dz, float* __restrict__ dl_out) {
+                                                         float* __restrict__ dz, float* __restrict__ dl_out, int clear) {
+    // clear != 0: write zeros to exactly the dz entries the normal pass writes (scn_readout_clear_dz)
     __shared__ float dl[RO_MAXD];
     __shared__ int nb[RO_MAXD];
     const int n = blockIdx.x, lane = threadIdx.x;
     const int s = n / ns, i = n - s * ns;
     const int vlast = last_nodes[n];
-    const float g = lane < max_deg ? d_logp[(size_t)n * max_deg + lane] : 0.f;
+    const float g = (!clear && lane < max_deg) ? d_logp[(size_t)n * max_deg + lane] : 0.f;
     const float gs = wave_sum(g);
     if (lane < max_deg) {
-        const float v = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
-        dl[lane] = v;
-        dl_out[(size_t)n * max_deg + lane] = v;
+        if (!clear) {
+            const float v = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
+            dl[lane] = v;
+            dl_out[(size_t)n * max_deg + lane] = v;
+        }
         nb[lane] = nbr[(size_t)vlast * max_deg + lane];
     }
     __syncthreads();
@@ -97,8 +100,12 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, in
                 if (nb[q] == other) dk = q;
             if (dk >= 0 && other < v) continue;          // handled from the other endpoint's side
             // the two endpoints carry opposite incidence signs (B1[tail]=-1, B1[head]=+1; a flip scales both)
-            const float coef = inc_sign[j] * (dl[d] - (dk >= 0 ? dl[dk] : 0.f));
             const size_t base = (((size_t)s * n_edges + e) * ns + i) * c;
+            if (clear) {
+                for (int cc = lane; cc < c; cc += 64) dz[base + cc] = 0.f;
+                continue;
+            }
+            const float coef = inc_sign[j] * (dl[d] - (dk >= 0 ? dl[dk] : 0.f));
             for (int cc = lane; cc < c; cc += 64)
                 dz[base + cc] = coef * w[cc] * act_grad_from_output(act, H[base + cc]);
         }
@@ -221,8 +228,8 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
                          const float* w_last, const int32_t* nbr, int32_t n_nodes, int32_t max_deg,
                          const int32_t* last_nodes, const int32_t* inc_ptr, const int32_t* inc_edge,
                          const float* inc_sign, const int32_t* edge_nodes, const float* bh, const float* d_logp,
-                         const float* logp, int32_t act, float* d_logits, float* dz, float* d_w_last,
-                         void* stream) {
+                         const float* logp, int32_t act, float* d_logits, float* dz, int32_t dz_is_zero,
+                         float* d_w_last, void* stream) {
     if (!H || !w_last || !nbr || !last_nodes || !inc_ptr || !inc_edge || !inc_sign || !edge_nodes || !bh ||
         !d_logp || !logp || !d_logits || !dz || !d_w_last)
         return SCN_ERR_BAD_ARG;
@@ -230,12 +237,25 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
     if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int N = n_slabs * ns;
-    SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
+    if (!dz_is_zero) SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
     float* dl = d_logits;
     hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
-                       last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl);
+                       last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(readout_dw_kernel, dim3(1), dim3(1024), 0, st, N * max_deg, c, dl, bh, d_w_last);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_readout_clear_dz(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c, const int32_t* nbr, int32_t n_nodes,
+                         int32_t max_deg, const int32_t* last_nodes, const int32_t* inc_ptr, const int32_t* inc_edge,
+                         const int32_t* edge_nodes, float* dz, void* stream) {
+    if (!nbr || !last_nodes || !inc_ptr || !inc_edge || !edge_nodes || !dz) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
+    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, nullptr,
+                       nullptr, nbr, max_deg, last_nodes, inc_ptr, inc_edge, nullptr, edge_nodes, nullptr, nullptr, 0, dz,
+                       nullptr, 1);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -325,6 +325,7 @@ class SconePlan:
         self.inc_ptr, self.inc_edge, self.inc_sign, self.edge_nodes = to(ptr), to(edge), to(sign), to(edge_nodes)
         self.nbr = to(bconds.nbrhoods.astype(np.int32))
         self.n_nodes, self.max_deg = bconds.nbrhoods.shape
+        self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
 
     # -- raw forward/backward over slabs (no autograd): used by the autograd Function and by the trainer
     def conv_stack(self, x, weights):
@@ -366,20 +367,33 @@ class SconePlan:
         hs, bh, y0 = saved
         H = hs[-1]
         S, E, ns, C = H.shape
-        dz = torch.empty_like(H)
+        # dz of the readout is zero except on the edges around the last nodes: keep one all-zero buffer per shape, let the
+        # readout fill its few rows and wipe exactly those again once the top layer has consumed it (no 16 GB memset)
+        key = (S, E, ns, C)
+        dz_top = self._dz_zero.pop(key, None)
+        if dz_top is None:
+            dz_top = torch.zeros_like(H)
         d_logits = torch.empty_like(logp)
         d_logp = d_logp.contiguous()
         check(lib.scn_readout_backward(S, ns, E, C, _dev(H), _dev(weights[-1]), _dev(self.nbr, torch.int32),
                                        self.n_nodes, self.max_deg, _dev(last_dev, torch.int32),
                                        _dev(self.inc_ptr, torch.int32), _dev(self.inc_edge, torch.int32),
                                        _dev(self.inc_sign), _dev(self.edge_nodes, torch.int32), _dev(bh),
-                                       _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz),
+                                       _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz_top), 1,
                                        _dev(grads[-1]), _stream()), "scn_readout_backward")
         L = len(hs) - 1
+        dz = dz_top
         for i in reversed(range(L)):
             if i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3]):
-                break                                   # first layer: shifted 1-channel input x one stream over dz
-            dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+                dz = None                               # first layer: shifted 1-channel input x one stream over dz
+            else:
+                dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+            if i == L - 1:                              # the top layer is done with the readout gradient: wipe and keep it
+                check(lib.scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
+                                               _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
+                                               _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
+                                               _dev(dz_top), _stream()), "scn_readout_clear_dz")
+                self._dz_zero[key] = dz_top
         return grads
 
 
