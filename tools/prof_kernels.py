@@ -30,6 +30,7 @@ W = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
 W1 = [torch.randn(1, C, device=dev) * 0.1 for _ in range(3)]
 x = torch.randn(S, E, 4, C, device=dev)
 x1 = torch.randn(S, E, 4, 1, device=dev)
+aux = torch.tanh(torch.randn(S, E, 4, C, device=dev)) if "bwd" in a.which.split(",") else x   # a layer output, distinct from dz
 which = a.which.split(",")
 def one_pass():
     if "spmm" in which:
@@ -39,7 +40,7 @@ def one_pass():
     if "fwd1" in which:
         plan.conv.forward([x1], W1, C, "tanh")
     if "bwd" in which:
-        plan.conv.backward([x], W, x, "tanh", True, [torch.zeros_like(w) for w in W])
+        plan.conv.backward([x], W, aux, "tanh", True, [torch.zeros_like(w) for w in W])
     if "bwd1" in which:
         plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
     if "dwf" in which:
@@ -50,7 +51,7 @@ if "fwd" in which:              # checksums: A/B builds of a kernel must agree o
     print("checksum fwd %.9e" % float(plan.conv.forward([x], W, C, "tanh").double().abs().sum()), flush=True)
 if "bwd" in which:
     dWs = [torch.zeros_like(w) for w in W]
-    dxx = plan.conv.backward([x], W, x, "tanh", True, dWs)
+    dxx = plan.conv.backward([x], W, aux, "tanh", True, dWs)
     print("checksum bwd %.9e %.9e" % (float(dxx.double().abs().sum()), float(sum(d.double().abs().sum() for d in dWs))), flush=True)
 one_pass()                      # untimed warm-up (first launches set function attributes, fault in pages)
 torch.cuda.synchronize()
