@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4, help="trajectories in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--spmm", type=int, default=1, help="also time the standalone dual SpMM (reported as extra)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")
+    ap.add_argument("--skip-modes", default="zeros,field",
+                    help="also time the same step in these zero-skipping modes (reported beside the dense value; '' = none)")
     return ap.parse_args()
 
 
@@ -189,6 +191,30 @@ def main():
                               "ms": ms2, "x": "[%d, %d, %d] dense random fp32" % (S, E, K)}
         del xr
 
+    # --- the same step with exact zero-skipping (work lists): identical results, reported BESIDE the dense headline value
+    skipping = {}
+    for mode in [m for m in args.skip_modes.split(",") if m]:
+        st_m = net.stage(inputs, y, np.arange(B), skip=mode)
+        if st_m[0][3] is None:
+            continue
+        net.grad_step_staged(inputs, st_m, total)                           # warm-up (allocates the pooled zero buffers)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            net.grad_step_staged(inputs, st_m, total)
+        sync()
+        dtm = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtm], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtm = float(t.item())
+        af = st_m[0][3]["active_fraction"]
+        skipping[mode] = {"value": total * args.steps / dtm, "unit": "trajectories/s", "ms_per_step": dtm / args.steps * 1e3,
+                          "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
+                          "note": "same step, same results; work items whose values are exactly zero"
+                                  + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
+        del st_m
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu = cpu_baseline(cx, sc, flows, choice, last, args.hidden, args.cpu_sample)
@@ -213,6 +239,8 @@ def main():
             "kernels": kernels, "setup_s": t_setup,
         }
         line.update(extra)
+        if skipping:
+            line["zero_skipping"] = skipping
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

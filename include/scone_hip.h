@@ -184,6 +184,32 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
 
+/* Zero-skipping mode.  Activations of this path have no bias terms, so a layer's output is exactly zero wherever the
+ * one-hop closure of its input's support does not reach; a trajectory batch on a large complex leaves most (block, slab)
+ * work items all-zero.  A work list names the items that may be non-zero: listed plan blocks (scn_conv_plan_blocks gives
+ * their row ranges) and, per block, the slabs to process.  The *_list entry points compute exactly these items and touch
+ * nothing else, so the output / gradient buffers must be all-zero outside them on entry (keep persistent zeroed buffers and
+ * wipe the listed items with scn_clear_list after use).  Results equal the dense calls.  All arrays are DEVICE pointers.
+ * Served by the LDS-blocked C = 32 kernels (and the first layer); other shapes return SCN_ERR_UNSUPPORTED. */
+typedef struct scn_work_list {
+    int32_t n_work;          /* listed blocks */
+    const int32_t* block;    /* [n_work]     plan block index */
+    const int32_t* ptr;      /* [n_work + 1] offsets into slab */
+    const int32_t* slab;     /* slabs of each listed block, ascending */
+} scn_work_list;
+
+/* first row of every plan block (host array of n_blocks + 1 entries; n_blocks from scn_conv_plan_info) */
+int scn_conv_plan_blocks(scn_conv_t conv, int32_t* row0_out);
+int scn_conv_forward_list(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
+                          const float* const* W, int32_t c_out, int32_t act, float* out, const scn_work_list* wl,
+                          void* stream);
+int scn_conv_backward_list(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,
+                           const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
+                           float* const* dW, void* workspace, size_t workspace_bytes, const scn_work_list* wl,
+                           void* stream);
+/* zero the listed items of a [n_slabs][n_rows][ns][channels] tensor */
+int scn_clear_list(scn_conv_t conv, int32_t ns, int32_t channels, float* tensor, const scn_work_list* wl, void* stream);
+
 /* First layer (c_in = 1) fast path.
  * scn_conv_forward_first = scn_conv_forward for one 1-channel input, which also stores the shifted input
  *   y[n_slabs][n_rows][ns][3] = (x, S_val0 x, S_val1 x)  -- the three scalars per point the kernel forms anyway.
@@ -195,10 +221,12 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
  * Both return SCN_ERR_UNSUPPORTED (workspace query: 0) when the operator has no blocked plan or the width is not 16 / 32;
  * callers then use scn_conv_forward / scn_conv_backward. */
 int scn_conv_forward_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x, const float* const* W,
-                           int32_t c_out, int32_t act, float* out, float* y_out, void* stream);
+                           int32_t c_out, int32_t act, float* out, float* y_out,
+                           const scn_work_list* wl /* NULL: dense */, void* stream);
 size_t scn_conv_dw_first_workspace(scn_conv_t conv, int32_t n_slabs, int32_t ns, int32_t c_dz);
 int scn_conv_dw_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x, const float* y, const float* dz,
-                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes, void* stream);
+                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes,
+                      const scn_work_list* wl /* NULL: dense; a list needs y */, void* stream);
 
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)

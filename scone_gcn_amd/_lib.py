@@ -19,6 +19,10 @@ SCN_MAX_SLOTS = 4
 ACT = {"none": 0, "tanh": 1, "relu": 2, "leaky_relu": 3}
 
 
+class WorkListDesc(ctypes.Structure):          # scn_work_list (device pointers)
+    _fields_ = [("n_work", ctypes.c_int32), ("block", ctypes.c_void_p), ("ptr", ctypes.c_void_p), ("slab", ctypes.c_void_p)]
+
+
 class GroupDesc(ctypes.Structure):
     _fields_ = [("n_cols", c_i32), ("identity", c_i32), ("n_vals", c_i32), ("reserved", c_i32),
                 ("nnz", c_i64), ("rowptr", c_void_p), ("col", c_void_p), ("val0", c_void_p), ("val1", c_void_p)]
@@ -63,9 +67,19 @@ SIGNATURES = {
                                          c_void_p]),
     "scn_conv_dw_first_workspace": (c_size_t, [c_void_p, c_i32, c_i32, c_i32]),
     "scn_conv_dw_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32,
-                                         ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+                                         ctypes.POINTER(c_void_p), c_void_p, c_size_t, ctypes.POINTER(WorkListDesc),
+                                         c_void_p]),
     "scn_conv_forward_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_i32, c_i32,
-                                              c_void_p, c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, ctypes.POINTER(WorkListDesc), c_void_p]),
+    "scn_conv_plan_blocks": (ctypes.c_int, [c_void_p, P_i32]),
+    "scn_conv_forward_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                             ctypes.POINTER(c_void_p), c_i32, c_i32, c_void_p,
+                                             ctypes.POINTER(WorkListDesc), c_void_p]),
+    "scn_conv_backward_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                              ctypes.POINTER(c_void_p), c_void_p, c_i32, c_i32, c_void_p,
+                                              ctypes.POINTER(c_void_p), c_void_p, c_size_t,
+                                              ctypes.POINTER(WorkListDesc), c_void_p]),
+    "scn_clear_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_plan_refine_order": (ctypes.c_int, [c_i32, P_i32, P_i32, c_i32, P_i32, c_void_p]),
     "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_void_p]),

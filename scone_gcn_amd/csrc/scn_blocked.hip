@@ -168,6 +168,8 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, ell_v, &P.dev.ell_v)) != SCN_OK) return st;
     if ((st = upload(c, self_slot, &P.dev.self_slot)) != SCN_OK) return st;
     P.mean_src_per_row = (double)total_src / std::max(1, n_rows);
+    P.h_row0 = blk_row0;
+    P.h_row0.push_back(n_rows);
     P.built = true;
     return SCN_OK;
 }
@@ -388,6 +390,22 @@ __device__ __forceinline__ void block_range(int n_blocks, int& first, int& last,
 
 #define SCN_SLAB_RANGE() \
     const int slab0 = (int)((int64_t)blockIdx.y * n_slabs / gridDim.y), slab1 = (int)((int64_t)(blockIdx.y + 1) * n_slabs / gridDim.y)
+
+// Work units of a kernel that accepts a WorkList `wl`: dense = (every block) x (this workgroup's slab range); listed = the
+// listed blocks, each with its own slab list (gridDim.y == 1).  SCN_UNIT_BEGIN opens the unit loop and defines b (block),
+// k0 / n_it (first entry / trip count) and SLAB_AT(it); all of it is wave-uniform (scalar loads).
+#define SCN_UNIT_RANGE()                                                             \
+    const bool listed = wl.block != nullptr;                                         \
+    int u_, u_end_, u_stride_;                                                       \
+    block_range(listed ? wl.n_work : P.n_blocks, u_, u_end_, u_stride_);             \
+    SCN_SLAB_RANGE()
+#define SCN_UNIT_BEGIN()                                                             \
+    for (; u_ < u_end_; u_ += u_stride_) {                                           \
+        const int b = listed ? wl.block[u_] : u_;                                    \
+        const int k0 = listed ? wl.ptr[u_] : slab0;                                  \
+        const int n_it = listed ? wl.ptr[u_ + 1] - k0 : slab1 - slab0;               \
+        if (n_it <= 0) continue;
+#define SLAB_AT(it) (listed ? wl.slab[k0 + (it)] : k0 + (it))
 
 // ------------------------------------------------------------------------------------------------
 // dual SpMM on K-float pieces (K % 4 == 0, K <= 128): ya = val0-operator * x, yb = val1-operator * x
@@ -763,7 +781,7 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                                                                      const float* __restrict__ W1,
                                                                      const float* __restrict__ W2,
                                                                      float* __restrict__ out, int n_rows, int n_cols,
-                                                                     int n_slabs) {
+                                                                     int n_slabs, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / W16_THREADS;   // 4 LDS-DMA instructions per wave
     const SmemC32 sm = carve_c32(smem);
@@ -786,10 +804,8 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
         *(bf16x8*)(base + 1024) = sp.mid;
         *(bf16x8*)(base + 2048) = sp.lo;
     }
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
-    if (slab0 >= slab1) return;
+    SCN_UNIT_RANGE();
+    if (!listed && slab0 >= slab1) return;
     f32x4 pend[2];
     float* pend_ptr = nullptr;
     bool pend_valid = false;
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) cqs[q] = (uint32_t)((n * 8 + kq * 2 + q) ^ (n >> 1)) << 4;
     const size_t slab_bytes = (size_t)n_cols * PIECE;
-    for (; b < b_end; b += b_stride) {
+    SCN_UNIT_BEGIN()
         wait_all_and_barrier();
         BlockMeta m;
         {
@@ -834,20 +850,21 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                                                  (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
         };
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) dma(i, (const char*)X + (size_t)slab0 * slab_bytes, sm.buf(0));
-        for (int slab = slab0; slab < slab1; ++slab) {
+        for (int i = 0; i < NDMA; ++i) dma(i, (const char*)X + (size_t)SLAB_AT(0) * slab_bytes, sm.buf(0));
+        for (int it = 0; it < n_it; ++it) {
+            const int slab = SLAB_AT(it);
             STAMP_START();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP_ADD(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             STAMP_ADD(1);
-            const bool more = slab + 1 < slab1;
-            const char* Xn = (const char*)X + (size_t)(slab + 1) * slab_bytes;
-            char* nbuf = sm.buf((slab + 1 - slab0) & 1);
+            const bool more = it + 1 < n_it;
+            const char* Xn = (const char*)X + (size_t)(more ? SLAB_AT(it + 1) : slab) * slab_bytes;
+            char* nbuf = sm.buf((it + 1) & 1);
             f32x4 z[3][2];                 // [segment][chunk q]: channels 8*kq + 4*q .. +3 of this lane's point
             {
-                const uint32_t cb[2] = {cqs[0] | (uint32_t)(((slab - slab0) & 1) << 16), cqs[1] | (uint32_t)(((slab - slab0) & 1) << 16)};
+                const uint32_t cb[2] = {cqs[0] | (uint32_t)((it & 1) << 16), cqs[1] | (uint32_t)((it & 1) << 16)};
                 gather_c32<2>(sm, rtc, m.w, tw, cb, z[0], z[1], z[2]);
             }
             STAMP_ADD(2);
@@ -1017,7 +1034,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
                                                                const float* __restrict__ W1,
                                                                const float* __restrict__ W2,
                                                                float* __restrict__ out, float* __restrict__ Yout,
-                                                               int n_rows, int n_cols, int n_slabs, int act) {
+                                                               int n_rows, int n_cols, int n_slabs, int act, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 16, CQ = C / 4;
     const Smem sm = carve(smem, PIECE);
@@ -1025,21 +1042,20 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
     const int tid = threadIdx.x;
     const int cq = tid % CQ;                                          // constant per thread: 512 % CQ == 0
     const f32x4 w0 = *(const f32x4*)(W0 + cq * 4), w1 = *(const f32x4*)(W1 + cq * 4), w2 = *(const f32x4*)(W2 + cq * 4);
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
-    if (slab0 >= slab1) return;
-    for (; b < b_end; b += b_stride) {
+    SCN_UNIT_RANGE();
+    if (!listed && slab0 >= slab1) return;
+    SCN_UNIT_BEGIN()
         wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
         __syncthreads();
-        dma_stage<PIECE, 0>((const char*)X + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
-        for (int slab = slab0; slab < slab1; ++slab) {
-            const float* st = (const float*)sm.buf((slab - slab0) & 1);
-            float* Zs = Z + ((slab - slab0) & 1) * (BK_R * BK_NS * 3);
+        dma_stage<PIECE, 0>((const char*)X + (size_t)SLAB_AT(0) * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        for (int it = 0; it < n_it; ++it) {
+            const int slab = SLAB_AT(it);
+            const float* st = (const float*)sm.buf(it & 1);
+            float* Zs = Z + (it & 1) * (BK_R * BK_NS * 3);
             wait_vm_and_barrier();
-            if (slab + 1 < slab1)
-                dma_stage<PIECE, 0>((const char*)X + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+            if (it + 1 < n_it)
+                dma_stage<PIECE, 0>((const char*)X + (size_t)SLAB_AT(it + 1) * n_cols * PIECE, sm.buf((it + 1) & 1), sm,
                                     m.nsrc);
             if (tid < m.rows * BK_NS) {
                 const int rt = tid >> 2, n = tid & 3;
@@ -1302,7 +1318,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                                                      const float* __restrict__ W2,
                                                                      const float* __restrict__ aux,
                                                                      float* __restrict__ dx, float* __restrict__ partial,
-                                                                     int n_rows, int n_cols, int n_slabs) {
+                                                                     int n_rows, int n_cols, int n_slabs, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
     const SmemC32 sm = carve_c32(smem);
@@ -1342,15 +1358,13 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dWacc[g][r] = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
+    SCN_UNIT_RANGE();
     uint32_t cqs[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cqs[q] = (uint32_t)((n * 8 + h * 4 + q) ^ (n >> 1)) << 4;
     const size_t slab_bytes = (size_t)n_cols * PIECE;
-    if (slab0 < slab1)
-    for (; b < b_end; b += b_stride) {
+    if (listed || slab0 < slab1)
+    SCN_UNIT_BEGIN()
         wait_all_and_barrier();
         const BlockMeta m = load_block_c32<BK_THREADS>(P, b, sm);
         __syncthreads();
@@ -1368,11 +1382,12 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         for (int i = 0; i < NDMA; ++i) {
             const int base = (i * BK_WAVES + wave) * 64;
             if (base + lane < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)DZ + (size_t)slab0 * slab_bytes + goff[i]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)DZ + (size_t)SLAB_AT(0) * slab_bytes + goff[i]),
                                                  (__attribute__((address_space(3))) void*)(sm.buf(0) + base * 16), 16, 0, 0);
         }
         const int rows_left = m.rows - wave * 8;
-        for (int slab = slab0; slab < slab1; ++slab) {
+        for (int it = 0; it < n_it; ++it) {
+            const int slab = SLAB_AT(it);
             const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * 32;
             const float* ap = aux + (rows_left > 0 ? tuni : 0);
             float* dp = dx ? dx + tuni : nullptr;
@@ -1399,7 +1414,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             __builtin_amdgcn_sched_barrier(0);
             f32x4 G[3][4];
             {
-                const uint32_t bufbit = (uint32_t)(((slab - slab0) & 1) << 16);
+                const uint32_t bufbit = (uint32_t)((it & 1) << 16);
                 const uint32_t cb[4] = {cqs[0] | bufbit, cqs[1] | bufbit, cqs[2] | bufbit, cqs[3] | bufbit};
                 gather_c32<4>(sm, rtc, m.w, tw, cb, G[0], G[1], G[2]);
             }
@@ -1408,9 +1423,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             // the first four groups
             f32x16 acc = zero16;
             f32x16 T[3];
-            const bool more = slab + 1 < slab1;
-            const char* Xn = (const char*)DZ + (size_t)(slab + 1) * slab_bytes;
-            char* nbuf = sm.buf((slab + 1 - slab0) & 1);
+            const bool more = it + 1 < n_it;
+            const char* Xn = (const char*)DZ + (size_t)(more ? SLAB_AT(it + 1) : slab) * slab_bytes;
+            char* nbuf = sm.buf((it + 1) & 1);
             auto side = [&](int k) {
                 if (k < NDMA) {
                     const int base = (k * BK_WAVES + wave) * 64;
@@ -1846,6 +1861,58 @@ __global__ __launch_bounds__(DWS_THREADS) void dw_first_stream_kernel(const floa
     }
 }
 
+// Zero-skipping variants of the two streaming pieces: one work item = (listed block, one of its slabs) = a contiguous run of
+// rows*ns points.  dw_first_list_kernel accumulates like dw_first_stream_kernel over the listed items only (everything else
+// of dz is exactly zero); clear_list_kernel writes zeros over the listed items of a [S][rows][ns][c] tensor, which returns
+// a buffer of the zero-skipping mode to its all-zero state.
+template <int C>
+__global__ __launch_bounds__(DWS_THREADS) void dw_first_list_kernel(PlanDev P, WorkList wl, const float* __restrict__ Y,
+                                                                    const float* __restrict__ DZ,
+                                                                    float* __restrict__ partial, int n_rows) {
+    constexpr int CQ = C / 4;
+    __shared__ f32x4 red[3 * DWS_THREADS];
+    const int tid = threadIdx.x;
+    f32x4 acc[3];
+    acc[0] = acc[1] = acc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = blockIdx.x; u < wl.n_work; u += gridDim.x) {
+        const int b = wl.block[u];
+        const int row0 = P.blk_row0[b], rows = P.blk_rows[b];
+        const int count = rows * BK_NS * CQ;                      // float4 items of the block's rows in one slab
+        for (int k = wl.ptr[u]; k < wl.ptr[u + 1]; ++k) {
+            const size_t p0 = ((size_t)wl.slab[k] * n_rows + row0) * BK_NS;   // first point
+            for (int i = tid; i < count; i += DWS_THREADS) {     // i % CQ == tid % CQ: DWS_THREADS % CQ == 0
+                const f32x4 d = *(const f32x4*)(DZ + (p0 * CQ + i) * 4);
+                const float* yp = Y + (p0 + i / CQ) * 3;
+                acc[0] += yp[0] * d;
+                acc[1] += yp[1] * d;
+                acc[2] += yp[2] * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) red[g * DWS_THREADS + tid] = acc[g];
+    __syncthreads();
+    if (tid < 3 * CQ) {
+        const int g = tid / CQ, cq = tid - g * CQ;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = cq; t < DWS_THREADS; t += CQ) sum += red[g * DWS_THREADS + t];
+        float* outp = partial + (size_t)blockIdx.x * (3 * C) + g * C + cq * 4;
+        outp[0] = sum[0]; outp[1] = sum[1]; outp[2] = sum[2]; outp[3] = sum[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void clear_list_kernel(PlanDev P, WorkList wl, float* __restrict__ T, int n_rows,
+                                                         int row_floats) {
+    for (int u = blockIdx.x; u < wl.n_work; u += gridDim.x) {
+        const int b = wl.block[u];
+        const int row0 = P.blk_row0[b], count = P.blk_rows[b] * row_floats / 4;
+        for (int k = wl.ptr[u]; k < wl.ptr[u + 1]; ++k) {
+            f32x4* t = (f32x4*)(T + ((size_t)wl.slab[k] * n_rows + row0) * row_floats);
+            for (int i = threadIdx.x; i < count; i += 256) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // dW_slot[0][cc] += sum over the stream kernel's partials: one wave per output element, lane l adds partials l, l+64, ...
 // and the 64 lane sums are folded in a fixed butterfly order (deterministic).
 __global__ __launch_bounds__(64) void dw_first_reduce_kernel(const float* __restrict__ partial, int n_partials, int c,
@@ -1911,8 +1978,10 @@ bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in,
 }
 
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
-                    const float* const* W, int c_out, int act, float* out, float* y_out, hipStream_t st) {
+                    const float* const* W, int c_out, int act, float* out, float* y_out, const WorkList* wlp,
+                    hipStream_t st) {
     const PlanDev& P = c->plan.dev;
+    const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const int ci = c_in[0];
     const int nr = c->n_rows, nc = c->g[0].n_cols;
@@ -1927,13 +1996,14 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
     hipLaunchKernelGGL(fwd_c32_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc, \
                        n_slabs)
         static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
-        if (!f32_mfma) {                                                   // default: the 16-wave bf16x3 kernel
+        if (wl.block) grid.y = 1;                                          // a work list carries its own slab lists
+        if (!f32_mfma || wl.block) {                                       // default: the 16-wave bf16x3 kernel
             const size_t lds16 = smem_bytes_c32(W16_WFRAG_BYTES + 16);
 #define SCN_LAUNCH_FWD32W(A)                                                                                      \
     do {                                                                                                          \
         SCN_ENSURE_LDS(fwd_c32_w16_kernel<A>, lds16);                                                             \
         hipLaunchKernelGGL(fwd_c32_w16_kernel<A>, grid, dim3(W16_THREADS), lds16, st, P, src[0], W[0], W[1], W[2], out, nr, \
-                           nc, n_slabs);                                                                          \
+                           nc, n_slabs, wl);                                                                      \
     } while (0)
             switch (act) {
                 case SCN_ACT_TANH: SCN_LAUNCH_FWD32W(SCN_ACT_TANH); break;
@@ -1951,6 +2021,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
             default: SCN_LAUNCH_FWD32(SCN_ACT_NONE); break;
         }
     } else if (ci == 16) {
+        if (wl.block) return SCN_ERR_UNSUPPORTED;
         const size_t lds = smem_bytes(256);
         SCN_ENSURE_LDS(fwd_c16_kernel, lds);
         launch_grid(c, n_slabs, lds, grid);
@@ -1959,12 +2030,13 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
     } else {
         const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
         launch_grid(c, n_slabs, lds, grid);
+        if (wl.block) grid.y = 1;
         if (c_out == 32)
             hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
-                               nc, n_slabs, act);
+                               nc, n_slabs, act, wl);
         else
             hipLaunchKernelGGL(fwd_c1_kernel<16>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
-                               nc, n_slabs, act);
+                               nc, n_slabs, act, wl);
     }
     SCN_LAUNCH_CHECK();
     return SCN_OK;
@@ -1993,8 +2065,9 @@ size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, cons
 
 int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
-                     float* const* dW, void* ws, size_t ws_bytes, hipStream_t st) {
+                     float* const* dW, void* ws, size_t ws_bytes, const WorkList* wlp, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
+    const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const int cd = c_dz[0];
     const int nr = c->n_rows, nc = c->g[0].n_cols;
@@ -2003,7 +2076,8 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     launch_grid(c, n_slabs, lds, grid);
     if (c_aux == 32) {
         static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
-        if (f32_mfma) {
+        if (wl.block) grid.y = 1;
+        if (f32_mfma && !wl.block) {
             SCN_ENSURE_LDS(bwd_c32_kernel, lds);
             hipLaunchKernelGGL(bwd_c32_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial,
                                nr, nc, n_slabs, act);
@@ -2012,7 +2086,7 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     do {                                                                                                          \
         SCN_ENSURE_LDS(bwd_c32_bf16_kernel<A>, lds);                                                              \
         hipLaunchKernelGGL(bwd_c32_bf16_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, \
-                           partial, nr, nc, n_slabs);                                                             \
+                           partial, nr, nc, n_slabs, wl);                                                         \
     } while (0)
             switch (act) {
                 case SCN_ACT_TANH: SCN_LAUNCH_BWD32(SCN_ACT_TANH); break;
@@ -2021,6 +2095,8 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
                 default: SCN_LAUNCH_BWD32(SCN_ACT_NONE); break;
             }
         }
+    } else if (wl.block) {
+        return SCN_ERR_UNSUPPORTED;                                  // work lists: C = 32 kernels only
     } else if (c_aux == 16) {
         SCN_ENSURE_LDS(bwd_c16_kernel, lds);
         hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
@@ -2054,11 +2130,25 @@ size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int 
     return dw_first_y_bytes(c, n_slabs) + (size_t)DWS_BLOCKS * 3 * cd * sizeof(float);
 }
 
-// y != nullptr: the shifted input saved by the forward (scn_conv_forward_first); otherwise it is computed here into ws
+// y != nullptr: the shifted input saved by the forward (scn_conv_forward_first); otherwise it is computed here into ws.
+// wlp: zero-skipping work list (requires y).
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd, float* const* dW,
-                     void* ws, hipStream_t st) {
+                     void* ws, const WorkList* wlp, hipStream_t st) {
     const PlanDev& P = c->plan.dev;
     float* partial = (float*)((char*)ws + dw_first_y_bytes(c, n_slabs));
+    if (wlp && wlp->block) {
+        if (!y) return SCN_ERR_BAD_ARG;
+        if (cd == 32)
+            hipLaunchKernelGGL(dw_first_list_kernel<32>, dim3(DWS_BLOCKS), dim3(DWS_THREADS), 0, st, P, *wlp, y, dz, partial,
+                               c->n_rows);
+        else
+            hipLaunchKernelGGL(dw_first_list_kernel<16>, dim3(DWS_BLOCKS), dim3(DWS_THREADS), 0, st, P, *wlp, y, dz, partial,
+                               c->n_rows);
+        SCN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(3 * cd), dim3(64), 0, st, partial, DWS_BLOCKS, cd, dW[0], dW[1], dW[2]);
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
     if (!y) {
         float* Y = (float*)ws;
         dim3 grid;
@@ -2075,6 +2165,15 @@ int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y,
         hipLaunchKernelGGL(dw_first_stream_kernel<16>, dim3(DWS_BLOCKS), dim3(DWS_THREADS), 0, st, y, dz, partial, n_points);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(3 * cd), dim3(64), 0, st, partial, DWS_BLOCKS, cd, dW[0], dW[1], dW[2]);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int blocked_clear_list(scn_conv_s* c, int ns, int ch, float* t, const WorkList* wl, hipStream_t st) {
+    if (!c->plan.built || ns != BK_NS || !wl || !wl->block || (ns * ch) % 4) return SCN_ERR_UNSUPPORTED;
+    if (wl->n_work == 0) return SCN_OK;
+    hipLaunchKernelGGL(clear_list_kernel, dim3(std::min(wl->n_work, 2048)), dim3(256), 0, st, c->plan.dev, *wl, t, c->n_rows,
+                       ns * ch);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

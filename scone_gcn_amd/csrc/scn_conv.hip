@@ -19,17 +19,19 @@ int build_block_plan(scn_conv_s* c);
 void free_block_plan(scn_conv_s* c);
 bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in, int c_out);
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
-                    const float* const* W, int c_out, int act, float* out, float* y_out, hipStream_t st);
+                    const float* const* W, int c_out, int act, float* out, float* y_out, const WorkList* wl,
+                    hipStream_t st);
 bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz, int c_aux, bool has_dx);
 size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux);
 int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
-                     float* const* dW, void* ws, size_t ws_bytes, hipStream_t st);
+                     float* const* dW, void* ws, size_t ws_bytes, const WorkList* wl, hipStream_t st);
 bool blocked_spmm_supported(const scn_conv_s* c, int k);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
-                     float* const* dW, void* ws, hipStream_t st);
+                     float* const* dW, void* ws, const WorkList* wl, hipStream_t st);
+int blocked_clear_list(scn_conv_s* c, int ns, int ch, float* t, const WorkList* wl, hipStream_t st);
 int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
@@ -367,9 +369,27 @@ int scn_conv_plan_info(scn_conv_t c, int32_t* n_blocks, float* mean_sources_per_
     return SCN_OK;
 }
 
+int scn_conv_plan_blocks(scn_conv_t c, int32_t* row0_out) {
+    if (!c || !row0_out) return SCN_ERR_BAD_ARG;
+    if (!c->plan.built) return SCN_ERR_UNSUPPORTED;
+    std::memcpy(row0_out, c->plan.h_row0.data(), c->plan.h_row0.size() * sizeof(int32_t));
+    return SCN_OK;
+}
+
+static bool valid_list(const scn_work_list* wl) {
+    return !wl || (wl->n_work >= 0 && wl->block && wl->ptr && (wl->slab || wl->n_work == 0));
+}
+static WorkList to_list(const scn_work_list* wl) { return WorkList{wl->n_work, wl->block, wl->ptr, wl->slab}; }
+
 int scn_conv_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
                      const float* const* W, int32_t c_out, int32_t act, float* out, void* stream) {
-    if (!c || !src || !c_in || !W || !out) return SCN_ERR_BAD_ARG;
+    return scn_conv_forward_list(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, stream);
+}
+
+int scn_conv_forward_list(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
+                          const float* const* W, int32_t c_out, int32_t act, float* out, const scn_work_list* wl,
+                          void* stream) {
+    if (!c || !src || !c_in || !W || !out || !valid_list(wl)) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || c_out <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     if (n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
     for (int g = 0; g < c->n_groups; ++g)
@@ -377,8 +397,11 @@ int scn_conv_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* con
     for (int s = 0; s < c->n_slots; ++s)
         if (!W[s]) return SCN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    WorkList wlist{0, nullptr, nullptr, nullptr};
+    if (wl) wlist = to_list(wl);
     if (blocked_forward_supported(c, ns, c_in, c_out))
-        return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, st);
+        return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, wl ? &wlist : nullptr, st);
+    if (wl) return SCN_ERR_UNSUPPORTED;            // work lists exist for the LDS-blocked kernels only
     FwdArgs a;
     std::memset(&a, 0, sizeof(a));
     fill_op(c, a.op);
@@ -416,34 +439,58 @@ size_t scn_conv_dw_first_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, in
 }
 
 int scn_conv_dw_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x, const float* y, const float* dz,
-                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!c || (!x && !y) || !dz || !dW || !dW[0] || !dW[1] || !dW[2] || !workspace) return SCN_ERR_BAD_ARG;
+                      int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes, const scn_work_list* wl,
+                      void* stream) {
+    if (!c || (!x && !y) || !dz || !dW || !dW[0] || !dW[1] || !dW[2] || !workspace || !valid_list(wl) || (wl && !y))
+        return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0) return SCN_ERR_BAD_SHAPE;
     if (!blocked_dw_first_supported(c, ns, c_dz)) return SCN_ERR_UNSUPPORTED;
     if (workspace_bytes < blocked_dw_first_workspace(c, n_slabs, ns, c_dz)) return SCN_ERR_WORKSPACE;
-    return blocked_dw_first(c, n_slabs, x, y, dz, c_dz, dW, workspace, (hipStream_t)stream);
+    WorkList wlist{0, nullptr, nullptr, nullptr};
+    if (wl) wlist = to_list(wl);
+    return blocked_dw_first(c, n_slabs, x, y, dz, c_dz, dW, workspace, wl ? &wlist : nullptr, (hipStream_t)stream);
 }
 
 int scn_conv_forward_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x, const float* const* W, int32_t c_out,
-                           int32_t act, float* out, float* y_out, void* stream) {
-    if (!c || !x || !W || !W[0] || !W[1] || !W[2] || !out || !y_out) return SCN_ERR_BAD_ARG;
+                           int32_t act, float* out, float* y_out, const scn_work_list* wl, void* stream) {
+    if (!c || !x || !W || !W[0] || !W[1] || !W[2] || !out || !y_out || !valid_list(wl)) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     const int32_t c_in = 1;
     if (c->n_groups != 1 || c->n_slots != 3 || !blocked_forward_supported(c, ns, &c_in, c_out)) return SCN_ERR_UNSUPPORTED;
-    return blocked_forward(c, n_slabs, ns, &x, &c_in, W, c_out, act, out, y_out, (hipStream_t)stream);
+    WorkList wlist{0, nullptr, nullptr, nullptr};
+    if (wl) wlist = to_list(wl);
+    return blocked_forward(c, n_slabs, ns, &x, &c_in, W, c_out, act, out, y_out, wl ? &wlist : nullptr, (hipStream_t)stream);
+}
+
+int scn_clear_list(scn_conv_t c, int32_t ns, int32_t channels, float* tensor, const scn_work_list* wl, void* stream) {
+    if (!c || !tensor || !wl || !valid_list(wl) || channels <= 0) return SCN_ERR_BAD_ARG;
+    WorkList wlist = to_list(wl);
+    return blocked_clear_list(c, ns, channels, tensor, &wlist, (hipStream_t)stream);
 }
 
 int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,
                       const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
                       float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!c || !dz || !c_dz || !W || !aux || !dW || !workspace) return SCN_ERR_BAD_ARG;
+    return scn_conv_backward_list(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes, nullptr,
+                                  stream);
+}
+
+int scn_conv_backward_list(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,
+                           const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
+                           float* const* dW, void* workspace, size_t workspace_bytes, const scn_work_list* wl,
+                           void* stream) {
+    if (!c || !dz || !c_dz || !W || !aux || !dW || !workspace || !valid_list(wl)) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || c_aux <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     for (int g = 0; g < c->n_groups; ++g)
         if (!dz[g] || c_dz[g] <= 0) return SCN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (workspace_bytes < scn_conv_backward_workspace(c, n_slabs, ns, c_dz, c_aux)) return SCN_ERR_WORKSPACE;
+    WorkList wlist{0, nullptr, nullptr, nullptr};
+    if (wl) wlist = to_list(wl);
     if (blocked_backward_supported(c, ns, c_dz, c_aux, dx != nullptr))
-        return blocked_backward(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes, st);
+        return blocked_backward(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes,
+                                wl ? &wlist : nullptr, st);
+    if (wl) return SCN_ERR_UNSUPPORTED;
 
     BwdArgs a;
     std::memset(&a, 0, sizeof(a));

@@ -101,10 +101,19 @@ struct PlanDev {
     const uint8_t* self_slot;   // [n_blocks][BK_R] slot of the row itself (identity shift)
 };
 
+// optional (block, slab) work list of the zero-skipping mode (scn_work_list); block == nullptr: every block, every slab
+struct WorkList {
+    int32_t n_work;
+    const int32_t* block;   // [n_work] plan block index
+    const int32_t* ptr;     // [n_work + 1] offsets into slab
+    const int32_t* slab;    // active slabs of each listed block, ascending
+};
+
 struct BlockPlan {
     bool built = false;
     PlanDev dev{};
     double mean_src_per_row = 0.0;
+    std::vector<int32_t> h_row0;   // first row of every block (+ n_rows): scn_conv_plan_blocks
     std::vector<void*> allocs;
 };
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT, GroupDesc, check, i32_array, ptr_array
+from ._lib import ACT, GroupDesc, WorkListDesc, check, i32_array, ptr_array
 from .complex import Shift, union_pattern
 from .synthetic_data_gen import SparseFlows
 
@@ -61,6 +61,25 @@ def _stream():
 def _dev(t, dtype=torch.float32):
     assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "expected a contiguous CUDA tensor"
     return ctypes.c_void_p(t.data_ptr())
+
+
+class WorkList:
+    """Device copy of a (block, slab) work list of the zero-skipping mode (scn_work_list).  Built from a boolean
+    scipy matrix A[slab, block]; `items` counts the (block, slab) pairs."""
+
+    def __init__(self, A, device):
+        import scipy.sparse as sp
+        At = sp.csr_matrix(A).T.tocsr()                     # rows = blocks, column indices = slabs (ascending)
+        At.sort_indices()
+        nz = np.flatnonzero(np.diff(At.indptr) > 0)
+        ptr = np.concatenate([[0], np.cumsum(np.diff(At.indptr)[nz])]).astype(np.int32)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(device)
+        self.block, self.ptr, self.slab = to(nz), to(ptr), to(At.indices)
+        self.n_work, self.items = int(len(nz)), int(At.nnz)
+        self.desc = WorkListDesc(self.n_work, self.block.data_ptr(), self.ptr.data_ptr(), self.slab.data_ptr())
+
+    def ref(self):
+        return ctypes.byref(self.desc)
 
 
 class ConvOp:
@@ -121,8 +140,10 @@ class ConvOp:
         check(_lib.load().scn_conv_plan_info(self.handle, ctypes.byref(nb), ctypes.byref(ms)), "scn_conv_plan_info")
         return nb.value, ms.value
 
-    def forward(self, srcs, Ws, c_out, act, out=None):
+    def forward(self, srcs, Ws, c_out, act, out=None, wl=None):
+        """wl: WorkList (zero-skipping): only the listed items of `out` are written; `out` must be given, all-zero."""
         lib = _lib.load()
+        assert wl is None or out is not None
         S, ns = srcs[0].shape[0], srcs[0].shape[2]
         assert len(srcs) == self.n_groups and len(Ws) == self.n_slots
         c_in = []
@@ -134,14 +155,16 @@ class ConvOp:
         if out is None:
             out = torch.empty((S, self.n_rows, ns, c_out), device=srcs[0].device, dtype=torch.float32)
         with _timed("conv_fwd c%s->%d" % ("+".join(map(str, c_in)), c_out)):
-            check(lib.scn_conv_forward(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
-                                       ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out), _stream()),
-                  "scn_conv_forward")
+            check(lib.scn_conv_forward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
+                                            ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out),
+                                            wl.ref() if wl is not None else None, _stream()), "scn_conv_forward")
         return out
 
-    def backward(self, dzs, Ws, aux, act, need_dx, dWs):
-        """dWs: list of tensors ACCUMULATED into.  Returns dx or None."""
+    def backward(self, dzs, Ws, aux, act, need_dx, dWs, dx=None, wl=None):
+        """dWs: list of tensors ACCUMULATED into.  Returns dx or None.  wl: WorkList (zero-skipping): only the listed
+        items of `dx` are written (it must be given, all-zero) and only they contribute to dWs."""
         lib = _lib.load()
+        assert wl is None or (dx is not None or not need_dx)
         S, ns, c_aux = aux.shape[0], aux.shape[2], aux.shape[3]
         assert aux.shape[1] == self.n_rows and len(dzs) == self.n_groups
         c_dz = []
@@ -153,33 +176,48 @@ class ConvOp:
         cdz = i32_array(c_dz)
         nbytes = lib.scn_conv_backward_workspace(self.handle, S, ns, cdz, c_aux)
         ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
-        dx = torch.empty_like(aux) if need_dx else None
+        if need_dx and dx is None:
+            dx = torch.empty_like(aux)
         with _timed("conv_bwd c%s->%d%s" % ("+".join(map(str, c_dz)), c_aux, "" if need_dx else " (dW only)")):
-            check(lib.scn_conv_backward(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
-                                        ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
-                                        _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
-                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-                  "scn_conv_backward")
-        return dx
+            check(lib.scn_conv_backward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
+                                             ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
+                                             _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
+                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                             wl.ref() if wl is not None else None, _stream()), "scn_conv_backward")
+        return dx if need_dx else None
 
-    def forward_first(self, x, Ws, c_out, act):
+    def forward_first(self, x, Ws, c_out, act, out=None, y=None, wl=None):
         """First layer (one 1-channel input): returns (out, y) with y = (x, S_lo x, S_up x) per point, or None when the
-        shape is not served (scn_conv_forward_first)."""
+        shape is not served (scn_conv_forward_first).  wl: as in forward (out and y given, all-zero)."""
         lib = _lib.load()
         S, rows, ns, c_in = x.shape
         if c_in != 1 or self.n_groups != 1 or self.n_slots != 3:
             return None
-        out = torch.empty((S, self.n_rows, ns, c_out), device=x.device, dtype=torch.float32)
-        y = torch.empty((S, self.n_rows, ns, 3), device=x.device, dtype=torch.float32)
+        assert wl is None or (out is not None and y is not None)
+        if out is None:
+            out = torch.empty((S, self.n_rows, ns, c_out), device=x.device, dtype=torch.float32)
+        if y is None:
+            y = torch.empty((S, self.n_rows, ns, 3), device=x.device, dtype=torch.float32)
         with _timed("conv_fwd c1->%d" % c_out):
             st = lib.scn_conv_forward_first(self.handle, S, ns, _dev(x), ptr_array([_dev(w).value for w in Ws]), c_out,
-                                            ACT[act], _dev(out), _dev(y), _stream())
+                                            ACT[act], _dev(out), _dev(y), wl.ref() if wl is not None else None, _stream())
         if st == -4:                                   # SCN_ERR_UNSUPPORTED
             return None
         check(st, "scn_conv_forward_first")
         return out, y
 
-    def dw_first(self, x, y, dz, dWs):
+    def clear(self, t, wl):
+        """Zero the listed items of a [S, rows, ns, C] tensor (scn_clear_list)."""
+        check(_lib.load().scn_clear_list(self.handle, t.shape[2], t.shape[3], _dev(t), wl.ref(), _stream()), "scn_clear_list")
+
+    def plan_blocks(self):
+        nb = self.plan_info()[0]
+        row0 = np.zeros(nb + 1, np.int32)
+        check(_lib.load().scn_conv_plan_blocks(self.handle, row0.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
+              "scn_conv_plan_blocks")
+        return row0
+
+    def dw_first(self, x, y, dz, dWs, wl=None):
         """First-layer weight gradient through the forward operator (scn_conv_dw_first); y: the shifted input saved by
         forward_first (or None: recomputed from x).  False if the shape is not served."""
         lib = _lib.load()
@@ -193,7 +231,7 @@ class ConvOp:
             check(lib.scn_conv_dw_first(self.handle, S, ns, _dev(x) if x is not None else None,
                                         _dev(y) if y is not None else None, _dev(dz), c,
                                         ptr_array([_dev(d).value for d in dWs]), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                        _stream()), "scn_conv_dw_first")
+                                        wl.ref() if wl is not None else None, _stream()), "scn_conv_dw_first")
         return True
 
     def spmm_dual(self, x, dual=True):
@@ -313,6 +351,7 @@ class SconePlan:
         self.n_edges = E
         lo, up = S_lower.device_csr(), S_upper.device_csr()
         hint = self.layout.block_starts[S_lower.row_level]
+        self._pattern = (abs(lo) + abs(up)).tocsr()
         self.conv = ConvOp(E, [{"mats": [lo, up], "identity": True, "n_cols": E}], hint)
         if S_lower.is_symmetric() and S_upper.is_symmetric():
             self.conv_T = self.conv
@@ -326,21 +365,95 @@ class SconePlan:
         self.nbr = to(bconds.nbrhoods.astype(np.int32))
         self.n_nodes, self.max_deg = bconds.nbrhoods.shape
         self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
+        self._h_nbr, self._h_inc_ptr, self._h_inc_edge = np.asarray(bconds.nbrhoods), np.asarray(ptr), np.asarray(edge)
+        self._zero_pool = {}                            # zero-skipping mode: all-zero activation / gradient buffers
+        self._blocks = None                             # (block of row, block adjacency), built on first use
 
     # -- raw forward/backward over slabs (no autograd): used by the autograd Function and by the trainer
-    def conv_stack(self, x, weights):
+    def conv_stack(self, x, weights, activity=None):
         n_layers = (len(weights) - 1) / 3
         assert n_layers % 1 == 0, "wrong number of weights"                    # TE:141-142
         hs, y0 = [x], None
+        S, E, ns, _ = x.shape
         for i in range(int(n_layers)):
             w = weights[3 * i:3 * i + 3]
-            first = self.conv.forward_first(x, w, w[0].shape[1], self.act) if i == 0 else None
+            c_out = w[0].shape[1]
+            wl = activity["fwd"][i] if activity else None
+            out = self._zeros((S, E, ns, c_out)) if activity else None
+            first = None
+            if i == 0:
+                first = self.conv.forward_first(x, w, c_out, self.act, out=out,
+                                                y=self._zeros((S, E, ns, 3)) if activity else None, wl=wl)
+                assert first is not None or not activity
             if first is not None:                       # 1-channel input: keep the shifted input for the weight gradient
                 hs.append(first[0])
                 y0 = first[1]
             else:
-                hs.append(self.conv.forward([hs[-1]], w, w[0].shape[1], self.act))
+                hs.append(self.conv.forward([hs[-1]], w, c_out, self.act, out=out, wl=wl))
         return hs, y0
+
+    # -- zero-skipping mode ---------------------------------------------------------------------------------
+    def _block_graph(self):
+        if self._blocks is None:
+            import scipy.sparse as sp
+            row0 = self.conv.plan_blocks()
+            nb = len(row0) - 1
+            blk_of = (np.searchsorted(row0, np.arange(self.n_edges), side="right") - 1).astype(np.int64)
+            lo = self._pattern
+            coo = lo.tocoo()
+            adj = sp.csr_matrix((np.ones(coo.nnz, np.int32), (blk_of[coo.row], blk_of[coo.col])), shape=(nb, nb))
+            adj = ((adj + adj.T + sp.identity(nb, dtype=np.int32, format="csr")) > 0).astype(np.int32).tocsr()
+            self._blocks = (blk_of, adj, nb)
+        return self._blocks
+
+    def activity(self, flow, last_nodes, n_layers, hidden, mode):
+        """Work lists of one micro-batch.  mode "zeros": every item whose value can be non-zero (a layer's output is
+        exactly zero outside the one-hop closure of its input's support); mode "field": additionally only what the loss
+        can see (the readout reads H_L on the edges around the last nodes; each layer below needs one more hop).
+        Block granularity, so both are supersets.  None when the shape is not served by the work-list kernels."""
+        import scipy.sparse as sp
+        if mode in (None, "dense") or hidden != 32 or not self.conv.plan_info()[0]:
+            return None
+        blk_of, adj, nb = self._block_graph()
+        perm = self.layout.perm[1]
+        flow = flow if isinstance(flow, SparseFlows) else SparseFlows.fromdense(np.asarray(flow))
+        N = len(flow)
+        S = pad_count(N, NS) // NS
+        traj = np.repeat(np.arange(N), np.diff(flow.ptr))
+        A = sp.csr_matrix((np.ones(len(traj), np.int32), (traj // NS, blk_of[perm[flow.idx]])), shape=(S, nb))
+        # rows the readout touches: edges incident to the neighbours of the last node (Bcond(last), TE:298-303)
+        last = np.asarray(last_nodes)[:N]
+        rr, cc = [], []
+        for n, v in enumerate(last):
+            for u in self._h_nbr[v]:
+                if u >= 0:
+                    e = self._h_inc_edge[self._h_inc_ptr[u]:self._h_inc_ptr[u + 1]]
+                    rr.append(np.full(len(e), n // NS))
+                    cc.append(blk_of[e])
+        R = sp.csr_matrix((np.ones(sum(map(len, rr)), np.int32), (np.concatenate(rr), np.concatenate(cc))), shape=(S, nb)) \
+            if rr else sp.csr_matrix((S, nb), dtype=np.int32)
+        hop = lambda M: ((M @ adj) > 0).astype(np.int32).tocsr()
+        sup = [(A > 0).astype(np.int32).tocsr()]
+        for _ in range(n_layers):
+            sup.append(hop(sup[-1]))                         # support of H_1 .. H_L
+        need = [None] * (n_layers + 1)
+        need[n_layers] = (R > 0).astype(np.int32).tocsr()     # gradient support of layer l's pre-activation = field of view
+        for l in range(n_layers - 1, 0, -1):
+            need[l] = hop(need[l + 1])
+        dev = self.device
+        fwd = [WorkList(sup[l].multiply(need[l]) if mode == "field" else sup[l], dev) for l in range(1, n_layers + 1)]
+        bwd = [None] + [WorkList(need[l], dev) for l in range(1, n_layers + 1)]
+        total = S * nb
+        return {"fwd": fwd, "bwd": bwd, "mode": mode,
+                "active_fraction": {"fwd": [w.items / total for w in fwd], "bwd": [w.items / total for w in bwd[1:]]}}
+
+    def _zeros(self, shape):
+        pool = self._zero_pool.setdefault(tuple(shape), [])
+        return pool.pop() if pool else torch.zeros(tuple(shape), device=self.device, dtype=torch.float32)
+
+    def _give_back(self, t, wl):
+        self.conv.clear(t, wl)                              # all-zero again
+        self._zero_pool.setdefault(tuple(t.shape), []).append(t)
 
     def readout(self, H, w_last, last_dev):
         lib = _lib.load()
@@ -356,15 +469,15 @@ class SconePlan:
                                       _dev(logp), _stream()), "scn_readout_forward")
         return logp, bh, logits
 
-    def forward(self, x, last_dev, weights):
-        hs, y0 = self.conv_stack(x, weights)
+    def forward(self, x, last_dev, weights, activity=None):
+        hs, y0 = self.conv_stack(x, weights, activity)
         logp, bh, _ = self.readout(hs[-1], weights[-1], last_dev)
-        return logp, (hs, bh, y0)
+        return logp, (hs, bh, y0, activity)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         """grads: list of tensors (same shapes as weights) accumulated into."""
         lib = _lib.load()
-        hs, bh, y0 = saved
+        hs, bh, y0, activity = saved
         H = hs[-1]
         S, E, ns, C = H.shape
         # dz of the readout is zero except on the edges around the last nodes: keep one all-zero buffer per shape, let the
@@ -384,16 +497,28 @@ class SconePlan:
         L = len(hs) - 1
         dz = dz_top
         for i in reversed(range(L)):
-            if i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3]):
+            wl_out = activity["bwd"][i] if (activity and i > 0) else None      # items of this layer's input gradient
+            wl_in = activity["bwd"][i + 1] if activity else None                # support of dz
+            dz_in = dz
+            if i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3], wl=wl_in):
                 dz = None                               # first layer: shifted 1-channel input x one stream over dz
             else:
-                dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+                assert not activity or i > 0, "zero-skipping needs the first-layer fast path"
+                dx = self._zeros(hs[i].shape) if activity else None
+                dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3],
+                                          dx=dx, wl=wl_out)
             if i == L - 1:                              # the top layer is done with the readout gradient: wipe and keep it
                 check(lib.scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
                                                _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
                                                _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
                                                _dev(dz_top), _stream()), "scn_readout_clear_dz")
                 self._dz_zero[key] = dz_top
+            elif activity:
+                self._give_back(dz_in, wl_in)
+        if activity:                                    # the forward's buffers go back to the pool, all-zero again
+            for l in range(1, L + 1):
+                self._give_back(hs[l], activity["fwd"][l - 1])
+            self._give_back(y0, activity["fwd"][0])
         return grads
 
 

@@ -47,7 +47,11 @@ def _n_samples(X):
 
 
 class Scone_GCN():
-    def __init__(self, epochs, step_size, batch_size, weight_decay, verbose=True, process_group=None):
+    def __init__(self, epochs, step_size, batch_size, weight_decay, verbose=True, process_group=None, skip_mode="dense"):
+        # skip_mode: "dense" (every block of every slab, the reference's formulation), "zeros" (skip work items whose
+        # values are exactly zero) or "field" (also skip what the loss cannot see); same results, see SconePlan.activity
+        assert skip_mode in ("dense", "zeros", "field")
+        self.skip_mode = skip_mode
         self.random_targets = None
         self.trained = False
         self.model = None
@@ -179,9 +183,11 @@ class Scone_GCN():
         return float((np.sum(t > r) + 0.5 * np.sum(t == r)) / np.sum(m))
 
     # ------------------------------------------------------------------ gradient step (STM:306-310)
-    def stage(self, inputs, y, idx):
-        """Move trajectories idx to the device as micro-batches of flow slabs: list of (x, last_nodes, y) with
-        x [S, E, ns, 1] fp32, last_nodes [S*ns] int32, y [S*ns, D] fp32 (zero rows for padding)."""
+    def stage(self, inputs, y, idx, skip=None):
+        """Move trajectories idx to the device as micro-batches of flow slabs: list of (x, last_nodes, y, activity) with
+        x [S, E, ns, 1] fp32, last_nodes [S*ns] int32, y [S*ns, D] fp32 (zero rows for padding) and the work lists of the
+        zero-skipping mode (None = dense; skip in {"dense", "zeros", "field"}, default self.skip_mode)."""
+        skip = self.skip_mode if skip is None else skip
         plan = self._plan(inputs)
         device = self._flat_w.device
         k = 7 if self.model_type == 'bunch' else 3
@@ -197,15 +203,18 @@ class Scone_GCN():
             D = np.asarray(y).shape[1]
             yt = torch.zeros((x.shape[0] * ops.NS, D), device=device, dtype=torch.float32)
             yt[:n] = torch.as_tensor(np.asarray(y)[sel], dtype=torch.float32).reshape(n, -1).to(device)
-            staged.append((x, last_dev, yt))
+            activity = None
+            if skip not in (None, "dense") and self.model_type != 'bunch':
+                activity = plan.activity(sub[2], np.asarray(sub[1]), len(self._shapes) // 3, self._shapes[0][1], skip)
+            staged.append((x, last_dev, yt, activity))
         return staged
 
     def _accumulate_staged(self, plan, staged, total):
         """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches.  Returns that partial loss
         as a 0-dim device tensor (no host synchronisation inside the step)."""
         part = torch.zeros((), device=self._flat_w.device, dtype=torch.float64)
-        for x, last_dev, yt in staged:
-            logp, saved = plan.forward(x, last_dev, self.weights)
+        for x, last_dev, yt, activity in staged:
+            logp, saved = plan.forward(x, last_dev, self.weights, activity) if activity else plan.forward(x, last_dev, self.weights)
             d_logp = yt * (-1.0 / total)
             part += (logp.double() * d_logp.double()).sum()
             plan.backward(saved, logp, d_logp, last_dev, self.weights, self._grads)

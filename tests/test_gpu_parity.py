@@ -376,6 +376,48 @@ def test_first_layer_fast_path_matches_generic_entry_points(cfg1, sc1, hidden):
             assert _maxdiff(a.cpu().numpy(), bb + 0.25) <= 2e-5 * max(1.0, np.abs(bb).max())
 
 
+@pytest.mark.parametrize("mode", ["zeros", "field"])
+def test_zero_skipping_modes_match_the_dense_step(mode):
+    """Work-list (zero-skipping) execution of a gradient step == the dense execution, on a complex large enough to have
+    inactive blocks: same loss, same weight gradients (to rounding of the summation order), buffers all-zero afterwards."""
+    _need_gpu()
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(20000)
+    sc = SimplicialComplex(cx)
+    paths = g.generate_random_walks(cx, m=24, seed=3, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=2)
+    N, D = len(paths), sc.max_degree
+    y = so.onehot_targets(choice, D)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    res = {}
+    for m in ("dense", mode):
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-3, N, 5e-5, verbose=False, skip_mode=m)
+        net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+        for w in net.weights:                                  # larger weights than 0.01 randn: gradients well above noise
+            w.mul_(20.0)
+        staged = net.stage(inputs, y, np.arange(N))
+        assert (staged[0][3] is None) == (m == "dense")
+        loss = float(net.grad_step_staged(inputs, staged, N, apply=False))
+        loss2 = float(net.grad_step_staged(inputs, staged, N, apply=False))     # pooled buffers must be clean again
+        assert loss2 == loss
+        res[m] = (loss, [gr.clone() for gr in net._grads], staged, net)
+    act = res[mode][2][0][3]
+    assert act is not None and max(act["active_fraction"]["fwd"]) < 0.9
+    assert abs(res[mode][0] - res["dense"][0]) <= 1e-6 * max(1.0, abs(res["dense"][0]))
+    for a, b in zip(res[mode][1], res["dense"][1]):
+        bb = b.cpu().numpy().astype(np.float64)
+        assert _maxdiff(a.cpu().numpy(), bb) <= 2e-5 * max(1.0, np.abs(bb).max())
+    plan = res[mode][3]._plan(inputs)
+    for pool in plan._zero_pool.values():
+        for t in pool:
+            assert float(t.abs().max()) == 0.0
+
+
 def test_errors_are_loud(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     shifts, readout, _ = te.setup_from_complex(sc1, "scone")
