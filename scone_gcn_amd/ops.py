@@ -406,6 +406,20 @@ class SconePlan:
             self._blocks = (blk_of, adj, nb)
         return self._blocks
 
+    def _readout_blocks(self):
+        """(n_nodes x n_blocks) 0/1: plan blocks holding an edge incident to a neighbour of the node (what Bcond(node) reads)."""
+        if getattr(self, "_ro_blocks", None) is None:
+            import scipy.sparse as sp
+            blk_of, _, nb = self._block_graph()
+            V, D = self._h_nbr.shape
+            r, c = np.nonzero(self._h_nbr >= 0)
+            nbr = sp.csr_matrix((np.ones(len(r), np.int32), (r, self._h_nbr[r, c])), shape=(V, V))
+            deg = np.diff(self._h_inc_ptr)
+            inc = sp.csr_matrix((np.ones(len(self._h_inc_edge), np.int32),
+                                 (np.repeat(np.arange(V), deg), blk_of[self._h_inc_edge])), shape=(V, nb))
+            self._ro_blocks = ((nbr @ inc) > 0).astype(np.int32).tocsr()
+        return self._ro_blocks
+
     def activity(self, flow, last_nodes, n_layers, hidden, mode):
         """Work lists of one micro-batch.  mode "zeros": every item whose value can be non-zero (a layer's output is
         exactly zero outside the one-hop closure of its input's support); mode "field": additionally only what the loss
@@ -423,15 +437,8 @@ class SconePlan:
         A = sp.csr_matrix((np.ones(len(traj), np.int32), (traj // NS, blk_of[perm[flow.idx]])), shape=(S, nb))
         # rows the readout touches: edges incident to the neighbours of the last node (Bcond(last), TE:298-303)
         last = np.asarray(last_nodes)[:N]
-        rr, cc = [], []
-        for n, v in enumerate(last):
-            for u in self._h_nbr[v]:
-                if u >= 0:
-                    e = self._h_inc_edge[self._h_inc_ptr[u]:self._h_inc_ptr[u + 1]]
-                    rr.append(np.full(len(e), n // NS))
-                    cc.append(blk_of[e])
-        R = sp.csr_matrix((np.ones(sum(map(len, rr)), np.int32), (np.concatenate(rr), np.concatenate(cc))), shape=(S, nb)) \
-            if rr else sp.csr_matrix((S, nb), dtype=np.int32)
+        sel = sp.csr_matrix((np.ones(N, np.int32), (np.arange(N) // NS, last)), shape=(S, self.n_nodes))
+        R = sel @ self._readout_blocks()
         hop = lambda M: ((M @ adj) > 0).astype(np.int32).tocsr()
         sup = [(A > 0).astype(np.int32).tocsr()]
         for _ in range(n_layers):
