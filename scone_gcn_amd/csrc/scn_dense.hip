@@ -3,7 +3,8 @@
 //   backward: dx[p,:]   = ( sum_k G'_k[p,:] @ W_k^T ) * act'(aux[p,:])      G'_k = S_k^T dZ_dst(k)
 //             dW_k     += sum_p aux[p,:]^T G'_k[p,:]                        (per-block partials, fixed-order reduce)
 // p runs over every (slab, row, trajectory) point of one level; all tensors are [points][channels] fp32.
-// VALU kernels (the three shifts of a Bunch level have different sources, so there is no shared gather to fuse with).
+// Generic widths run on VALU kernels; the width that matters at scale (every term and the output 32 channels wide) runs on
+// v_mfma_f32_32x32x2_f32 with the operands streamed straight from HBM (no gather here, so no LDS staging either).
 #include <algorithm>
 #include <cstring>
 
@@ -139,6 +140,137 @@ __global__ __launch_bounds__(DN_THREADS) void dense_bwd_kernel(DenseBwdArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA path: every term and the output are 32 channels wide.  One wave = tiles of 32 points:
+//   lane = (point p = lane & 31, half h = lane >> 5) loads its point's channels 16h .. 16h+15 of every term (4 x 16 B),
+//   A[m = point][k] = G_k[point][16h + s], B[k][n] = W_k[16h + s][n] (registers), D[m = pt(r, h)][n = lane & 31].
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int DM_WAVES = 4, DM_THREADS = 64 * DM_WAVES;
+constexpr int DM_PSTRIDE = 36;                   // floats per point row of the transpose patch
+
+template <int ACT>
+__global__ __launch_bounds__(DM_THREADS, 2) void dense_fwd_mfma_kernel(DenseFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    float Bt[DN_MAX_TERMS][16];
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) Bt[k][s] = k < a.n_terms ? a.W[k][(16 * h + s) * 32 + p] : 0.f;
+    const int64_t n_tiles = (a.n_points + 31) / 32;
+    for (int64_t t = (int64_t)blockIdx.x * DM_WAVES + wave; t < n_tiles; t += (int64_t)gridDim.x * DM_WAVES) {
+        const int64_t p0 = t * 32;
+        const int64_t pt = std::min<int64_t>(p0 + p, a.n_points - 1);          // clamp: tail lanes re-read the last point
+        f32x4 g[DN_MAX_TERMS][4];
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[k][q] = *(const f32x4*)(a.G[k] + pt * 32 + 16 * h + 4 * q);
+            }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g[k][s >> 2][s & 3], Bt[k][s], acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t q = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (q < a.n_points) a.out[q * 32 + p] = act_apply_fast(ACT, acc[r]);
+        }
+    }
+}
+
+// backward: dX tile by MFMA against W_k^T, dW_k += aux^T G_k by a second MFMA whose B operand (a channel's 32 points) comes
+// through a per-wave LDS transpose patch; per-block partials in the layout dense_dw_reduce expects.
+template <int ACT>
+__global__ __launch_bounds__(DM_THREADS, 2) void dense_bwd_mfma_kernel(DenseBwdArgs a) {
+    __shared__ float lds[DM_WAVES * 32 * DM_PSTRIDE];               // patches; reused for the final cross-wave reduction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    float* patch = lds + wave * 32 * DM_PSTRIDE;
+    float Bt[DN_MAX_TERMS][16];                                       // B[k = c][n = ca] = W_k[ca = p][c = 16h + s]
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) Bt[k][s] = k < a.n_terms ? a.W[k][p * 32 + 16 * h + s] : 0.f;
+    f32x16 dWacc[DN_MAX_TERMS];
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWacc[k][r] = 0.f;
+    const int64_t n_tiles = (a.n_points + 31) / 32;
+    for (int64_t t = (int64_t)blockIdx.x * DM_WAVES + wave; t < n_tiles; t += (int64_t)gridDim.x * DM_WAVES) {
+        const int64_t p0 = t * 32;
+        const bool mine = p0 + p < a.n_points;
+        const int64_t pt = mine ? p0 + p : a.n_points - 1;
+        f32x4 g[DN_MAX_TERMS][4];
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *(const f32x4*)(a.G[k] + pt * 32 + 16 * h + 4 * q);
+                    g[k][q] = mine ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        float ax[16];                                                  // aux in the D layout: point pt(r, h), channel p
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t q = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            ax[r] = q < a.n_points ? a.aux[q * 32 + p] : 0.f;
+        }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g[k][s >> 2][s & 3], Bt[k][s], acc, 0, 0, 0);
+            }
+        if (a.dx) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t q = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (q < a.n_points) a.dx[q * 32 + p] = acc[r] * act_grad_from_output(ACT, ax[r]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(patch + p * DM_PSTRIDE + 16 * h + 4 * q) = g[k][q];
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {                         // k-step s contracts points pt(s, h)
+                    const int ps = (s & 3) + 8 * (s >> 2) + 4 * h;
+                    dWacc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], patch[ps * DM_PSTRIDE + p], dWacc[k], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+    // dWacc[k][r] = dW_k[ca = pt(r, h)][c = p]: add the four waves in a fixed order, emit this block's partial
+    int woff[DN_MAX_TERMS + 1];
+    woff[0] = 0;
+    for (int k = 0; k < a.n_terms; ++k) woff[k + 1] = woff[k] + 1024;
+    float* outp = a.partial + (size_t)blockIdx.x * woff[a.n_terms];
+    for (int k = 0; k < a.n_terms; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ca = (r & 3) + 8 * (r >> 2) + 4 * h;
+            lds[wave * 1024 + ca * 32 + p] = dWacc[k][r];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += DM_THREADS)
+            outp[woff[k] + i] = (lds[i] + lds[1024 + i]) + (lds[2048 + i] + lds[3072 + i]);
+    }
+}
+
 struct DenseReduceArgs {
     const float* partial;
     int32_t n_partials, total, n_terms;
@@ -178,6 +310,20 @@ int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* cons
         a.c_in[k] = c_in[k]; a.G[k] = G[k]; a.W[k] = W[k];
         lds += (size_t)c_in[k] * c_out * sizeof(float);
     }
+    bool all32 = c_out == 32;
+    for (int k = 0; k < n_terms; ++k) all32 = all32 && c_in[k] == 32;
+    if (all32) {
+        const int blocks = (int)std::min<int64_t>(2048, ((n_points + 31) / 32 + DM_WAVES - 1) / DM_WAVES);
+        hipStream_t st = (hipStream_t)stream;
+        switch (act) {
+            case SCN_ACT_TANH: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_TANH>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
+            case SCN_ACT_RELU: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_RELU>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
+            case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_LEAKY_RELU>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
+            default: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_NONE>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
+        }
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
     if (lds > 64 * 1024) return SCN_ERR_UNSUPPORTED;
     const int64_t total = n_points * ((c_out + 3) / 4);
     const int blocks = (int)std::min<int64_t>(8192, (total + DN_THREADS - 1) / DN_THREADS);
@@ -215,10 +361,21 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
         r.off[k + 1] = r.off[k] + c_aux * c[k];
         r.dW[k] = dW[k];
     }
-    if (lds > 64 * 1024) return SCN_ERR_UNSUPPORTED;
     const int nb = dense_blocks(n_points);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dense_bwd_kernel, dim3(nb), dim3(DN_THREADS), lds, st, a);
+    bool all32 = c_aux == 32;
+    for (int k = 0; k < n_terms; ++k) all32 = all32 && c[k] == 32;
+    if (all32) {
+        switch (act) {
+            case SCN_ACT_TANH: hipLaunchKernelGGL(dense_bwd_mfma_kernel<SCN_ACT_TANH>, dim3(nb), dim3(DM_THREADS), 0, st, a); break;
+            case SCN_ACT_RELU: hipLaunchKernelGGL(dense_bwd_mfma_kernel<SCN_ACT_RELU>, dim3(nb), dim3(DM_THREADS), 0, st, a); break;
+            case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL(dense_bwd_mfma_kernel<SCN_ACT_LEAKY_RELU>, dim3(nb), dim3(DM_THREADS), 0, st, a); break;
+            default: hipLaunchKernelGGL(dense_bwd_mfma_kernel<SCN_ACT_NONE>, dim3(nb), dim3(DM_THREADS), 0, st, a); break;
+        }
+    } else {
+        if (lds > 64 * 1024) return SCN_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(dense_bwd_kernel, dim3(nb), dim3(DN_THREADS), lds, st, a);
+    }
     SCN_LAUNCH_CHECK();
     r.partial = a.partial; r.n_partials = nb; r.total = r.off[n_terms]; r.n_terms = n_terms;
     hipLaunchKernelGGL(dense_dw_reduce, dim3((r.total + 255) / 256), dim3(256), 0, st, r);

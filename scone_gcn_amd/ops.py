@@ -349,6 +349,19 @@ class SconePlan:
         self.device = device
         E = S_lower.shape[0]
         self.n_edges = E
+        self._init_operators(S_lower, S_upper)
+        ptr, edge, sign, edge_nodes = bconds.incidence_tables()
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.inc_ptr, self.inc_edge, self.inc_sign, self.edge_nodes = to(ptr), to(edge), to(sign), to(edge_nodes)
+        self.nbr = to(bconds.nbrhoods.astype(np.int32))
+        self.n_nodes, self.max_deg = bconds.nbrhoods.shape
+        self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
+        self._h_nbr, self._h_inc_ptr, self._h_inc_edge = np.asarray(bconds.nbrhoods), np.asarray(ptr), np.asarray(edge)
+        self._zero_pool = {}                            # zero-skipping mode: all-zero activation / gradient buffers
+        self._blocks = None                             # (block of row, block adjacency), built on first use
+
+    def _init_operators(self, S_lower, S_upper):
+        E = self.n_edges
         lo, up = S_lower.device_csr(), S_upper.device_csr()
         hint = self.layout.block_starts[S_lower.row_level]
         self._pattern = (abs(lo) + abs(up)).tocsr()
@@ -359,15 +372,6 @@ class SconePlan:
             self.conv_T = ConvOp(E, [{"mats": [lo.T.tocsr(), up.T.tocsr()], "identity": True, "n_cols": E}], hint)
         self.nnz_pattern = self.conv.nnz[0]
         self.nnz_lower, self.nnz_upper = int(lo.nnz), int(up.nnz)
-        ptr, edge, sign, edge_nodes = bconds.incidence_tables()
-        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        self.inc_ptr, self.inc_edge, self.inc_sign, self.edge_nodes = to(ptr), to(edge), to(sign), to(edge_nodes)
-        self.nbr = to(bconds.nbrhoods.astype(np.int32))
-        self.n_nodes, self.max_deg = bconds.nbrhoods.shape
-        self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
-        self._h_nbr, self._h_inc_ptr, self._h_inc_edge = np.asarray(bconds.nbrhoods), np.asarray(ptr), np.asarray(edge)
-        self._zero_pool = {}                            # zero-skipping mode: all-zero activation / gradient buffers
-        self._blocks = None                             # (block of row, block adjacency), built on first use
 
     # -- raw forward/backward over slabs (no autograd): used by the autograd Function and by the trainer
     def conv_stack(self, x, weights, activity=None):
@@ -481,14 +485,11 @@ class SconePlan:
         logp, bh, _ = self.readout(hs[-1], weights[-1], last_dev)
         return logp, (hs, bh, y0, activity)
 
-    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
-        """grads: list of tensors (same shapes as weights) accumulated into."""
+    def _readout_grad(self, H, bh, logp, d_logp, last_dev, weights, grads):
+        """Gradient of the readout w.r.t. the last layer's pre-activation, into a pooled all-zero buffer (it is zero except
+        on the edges around the last nodes; _release_top wipes exactly those rows again -- no 16 GB memset)."""
         lib = _lib.load()
-        hs, bh, y0, activity = saved
-        H = hs[-1]
         S, E, ns, C = H.shape
-        # dz of the readout is zero except on the edges around the last nodes: keep one all-zero buffer per shape, let the
-        # readout fill its few rows and wipe exactly those again once the top layer has consumed it (no 16 GB memset)
         key = (S, E, ns, C)
         dz_top = self._dz_zero.pop(key, None)
         if dz_top is None:
@@ -501,6 +502,22 @@ class SconePlan:
                                        _dev(self.inc_sign), _dev(self.edge_nodes, torch.int32), _dev(bh),
                                        _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz_top), 1,
                                        _dev(grads[-1]), _stream()), "scn_readout_backward")
+        return dz_top, key
+
+    def _release_top(self, dz_top, key, last_dev):
+        S, E, ns, C = key
+        check(_lib.load().scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
+                                               _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
+                                               _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
+                                               _dev(dz_top), _stream()), "scn_readout_clear_dz")
+        self._dz_zero[key] = dz_top
+
+    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        """grads: list of tensors (same shapes as weights) accumulated into."""
+        lib = _lib.load()
+        hs, bh, y0, activity = saved
+        dz_top, key = self._readout_grad(hs[-1], bh, logp, d_logp, last_dev, weights, grads)
+        S, E, ns, C = hs[-1].shape
         L = len(hs) - 1
         dz = dz_top
         for i in reversed(range(L)):
@@ -515,17 +532,64 @@ class SconePlan:
                 dz = self.conv_T.backward([dz], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3],
                                           dx=dx, wl=wl_out)
             if i == L - 1:                              # the top layer is done with the readout gradient: wipe and keep it
-                check(lib.scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
-                                               _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
-                                               _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
-                                               _dev(dz_top), _stream()), "scn_readout_clear_dz")
-                self._dz_zero[key] = dz_top
+                self._release_top(dz_top, key, last_dev)
             elif activity:
                 self._give_back(dz_in, wl_in)
         if activity:                                    # the forward's buffers go back to the pool, all-zero again
             for l in range(1, L + 1):
                 self._give_back(hs[l], activity["fwd"][l - 1])
             self._give_back(y0, activity["fwd"][0])
+        return grads
+
+
+class PowerPlan(SconePlan):
+    """scone-like model whose second shift is the SQUARE of the first (Ebli / SNN: L1 and L1^2, TE:251-253), for complexes
+    where the rows of the square no longer fit the LDS-blocked plan (> 128 distinct sources).  The square is never formed:
+    per layer  G1 = S H,  G2 = S G1  on the LDS-blocked SpMM, then  act(H W0 + G1 W1 + G2 W2)  and its backward on the dense
+    term kernels (scn_dense_terms_*) -- the same composition the Bunch plan uses."""
+
+    def _init_operators(self, S_lower, S_upper):
+        E = self.n_edges
+        m = S_lower.device_csr()
+        hint = self.layout.block_starts[S_lower.row_level]
+        self.op = ConvOp(E, [{"mats": [m], "identity": False, "n_cols": E}], hint)
+        self.op_T = self.op if S_lower.is_symmetric() else ConvOp(E, [{"mats": [m.T.tocsr()], "identity": False, "n_cols": E}], hint)
+        self.conv = self.conv_T = None
+        self.nnz_pattern = self.nnz_lower = int(m.nnz)
+        self.nnz_upper = int(S_upper.csr.nnz)
+
+    @staticmethod
+    def _shift(op, x):
+        S, R, ns, c = x.shape
+        y, _ = op.spmm_dual(x.view(S, R, ns * c), dual=False)
+        return y.view(S, R, ns, c)
+
+    def activity(self, *a, **k):
+        return None
+
+    def conv_stack(self, x, weights, activity=None):
+        n_layers = (len(weights) - 1) / 3
+        assert n_layers % 1 == 0, "wrong number of weights"                    # TE:159-160
+        hs = [x]
+        for i in range(int(n_layers)):
+            w = weights[3 * i:3 * i + 3]
+            g1 = self._shift(self.op, hs[-1])
+            g2 = self._shift(self.op, g1)
+            hs.append(dense_terms_forward([hs[-1], g1, g2], w, w[0].shape[1], self.act))
+        return hs, None
+
+    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        hs, bh, _, _ = saved
+        dz_top, key = self._readout_grad(hs[-1], bh, logp, d_logp, last_dev, weights, grads)
+        L = len(hs) - 1
+        dz = dz_top
+        for i in reversed(range(L)):
+            g1 = self._shift(self.op_T, dz)
+            g2 = self._shift(self.op_T, g1)
+            dx = dense_terms_backward([dz, g1, g2], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+            if i == L - 1:
+                self._release_top(dz_top, key, last_dev)
+            dz = dx
         return grads
 
 
@@ -713,8 +777,23 @@ class _BunchFn(torch.autograd.Function):
 def get_scone_plan(S_lower, S_upper, bconds, act, device):
     key = ("scone", id(S_upper), id(bconds), act, str(device))
     if key not in S_lower._cache:
-        S_lower._cache[key] = SconePlan(S_lower, S_upper, bconds, act, device)
+        plan = None
+        wide = S_upper.csr.nnz and int(np.diff(S_upper.csr.indptr).max()) >= 128      # such a row cannot enter a block
+        if wide and _is_square_of(S_upper, S_lower):
+            # rows of S^2 with more than 128 sources do not fit the LDS-blocked plan: compose S (S H) instead of fusing S^2
+            plan = PowerPlan(S_lower, S_upper, bconds, act, device)
+            if plan.op.plan_info()[0] == 0:
+                plan = None
+        S_lower._cache[key] = plan if plan is not None else SconePlan(S_lower, S_upper, bconds, act, device)
     return S_lower._cache[key]
+
+
+def _is_square_of(S2, S):
+    if S.shape[0] != S.shape[1] or S2.shape != S.shape:
+        return False
+    d = (S2.csr - S.csr @ S.csr).tocsr()
+    scale = max(1.0, float(abs(S2.csr).max()) if S2.csr.nnz else 1.0)
+    return d.nnz == 0 or float(abs(d).max()) <= 1e-9 * scale
 
 
 def get_bunch_plan(shifts, nbrhoods, device):

@@ -418,6 +418,35 @@ def test_zero_skipping_modes_match_the_dense_step(model, mode):
             assert float(t.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("hidden", [8, 32])
+def test_ebli_composed_plan_matches_fused_operator(cfg1, sc1, hidden):
+    """PowerPlan (S (S H) on the blocked SpMM + dense term kernels; what Ebli uses when L1^2 outgrows the block plan) against
+    the plan that applies the stored L1^2: same log-probabilities, same gradients."""
+    from scone_gcn_amd import ops
+    L1, L1sq = sc1.ebli_shifts()
+    assert ops._is_square_of(L1sq, L1) and not ops._is_square_of(L1, L1sq)
+    dev = ops.default_device()
+    fused = ops.SconePlan(L1, L1sq, sc1.bconds(), "leaky_relu", dev)
+    comp = ops.PowerPlan(L1, L1sq, sc1.bconds(), "leaky_relu", dev)
+    sel = np.arange(40, 52)
+    x, n = ops.flows_to_slabs(cfg1["flows"][sel], sc1.layout, dev)
+    last = ops._last_nodes_dev(cfg1["last_nodes"][sel], x.shape[0] * ops.NS, dev)
+    shapes = so.weight_shapes(1, [(3, hidden)] * 2, 1)
+    w = [torch.tensor(a, dtype=torch.float32, device="cuda") for a in _rand_weights(shapes, 0.05, 9)]
+    rs = np.random.RandomState(2)
+    res = []
+    for plan in (fused, comp):
+        logp, saved = plan.forward(x, last, w)
+        d_logp = torch.tensor(rs.randn(*logp.shape).astype(np.float32), device="cuda") if not res else res[0][2]
+        grads = [torch.zeros_like(a) for a in w]
+        plan.backward(saved, logp, d_logp, last, w, grads)
+        res.append((logp, grads, d_logp))
+    assert _maxdiff(res[1][0].cpu().numpy(), res[0][0].cpu().numpy().astype(np.float64)) <= TOL
+    for a, b in zip(res[1][1], res[0][1]):
+        bb = b.cpu().numpy().astype(np.float64)
+        assert _maxdiff(a.cpu().numpy(), bb) <= 2e-5 * max(1.0, np.abs(bb).max())
+
+
 def test_errors_are_loud(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     shifts, readout, _ = te.setup_from_complex(sc1, "scone")
