@@ -271,6 +271,30 @@ __global__ __launch_bounds__(DM_THREADS, 2) void dense_bwd_mfma_kernel(DenseBwdA
     }
 }
 
+// one output channel (the last Bunch layer, TE:198) with terms of width % 4 == 0: thread = (point, 16-byte chunk of a term
+// row) so that a wave reads whole rows coalesced; the chunk dot products are folded over the CQ lanes of a point.
+template <int CQ>      // chunks per point row (c_in / 4): 4 or 8
+__global__ __launch_bounds__(256) void dense_fwd_out1_kernel(DenseFwdArgs a) {
+    const int cq = threadIdx.x % CQ;
+    f32x4 w[DN_MAX_TERMS];
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k) w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t total = a.n_points * CQ;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total + (CQ - 1); i += (int64_t)gridDim.x * 256) {
+        const bool ok = i < total;                                      // keep whole lane groups inside the shuffles
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms && ok) {
+                const f32x4 g = *(const f32x4*)(a.G[k] + i * 4);
+                s += g[0] * w[k][0] + g[1] * w[k][1] + g[2] * w[k][2] + g[3] * w[k][3];
+            }
+#pragma unroll
+        for (int m = 1; m < CQ; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (ok && cq == 0) a.out[i / CQ] = act_apply_fast(a.act, s);
+    }
+}
+
 struct DenseReduceArgs {
     const float* partial;
     int32_t n_partials, total, n_terms;
@@ -321,6 +345,16 @@ int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* cons
             case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_LEAKY_RELU>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
             default: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_NONE>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
         }
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
+    bool same = c_out == 1 && (c_in[0] == 16 || c_in[0] == 32);
+    for (int k = 1; k < n_terms; ++k) same = same && c_in[k] == c_in[0];
+    if (same) {                                                     // one output channel, equal term widths 16 / 32
+        const int cqn = c_in[0] / 4;
+        const int blocks = (int)std::min<int64_t>(8192, (n_points * cqn + 255) / 256);
+        if (cqn == 8) hipLaunchKernelGGL(dense_fwd_out1_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(dense_fwd_out1_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         SCN_LAUNCH_CHECK();
         return SCN_OK;
     }
