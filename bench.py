@@ -177,6 +177,18 @@ def main():
                for k, (n, ms_) in ksum.items()}
 
     extra = {}
+    if rank == 0:                                    # measured device-copy ceiling: 4 GiB read + 4 GiB write
+        src = torch.empty(1 << 30, device="cuda", dtype=torch.float32)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["measured_copy_GBps"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
     if args.spmm and rank == 0:
         K = 128
         S = 32

@@ -101,7 +101,7 @@ int build_block_plan(scn_conv_s* c) {
     const bool has_v1 = G.n_vals > 1, has_id = G.identity == 1;
     const int n_rows = c->n_rows;
     std::vector<int32_t> blk_row0, src_ptr(1, 0), src_rows, ell_ptr;
-    std::vector<uint8_t> blk_rows, width, tile_w, ell_slot, self_slot;
+    std::vector<uint8_t> blk_rows, width, tile_w, tile_w4, ell_slot, self_slot;
     std::vector<float2> ell_v;
     std::vector<int32_t> mark(G.n_cols, -1), local(G.n_cols, 0), cur;
     cur.reserve(BK_SRC + 64);
@@ -128,8 +128,8 @@ int build_block_plan(scn_conv_s* c) {
         const size_t base = ell_slot.size();                 // entries are [row][w], w even, zero padded
         ell_slot.resize(base + (size_t)w * rows, 0);
         ell_v.resize(base + (size_t)w * rows, float2{0.f, 0.f});
-        uint8_t tw[BK_WAVES];
-        for (int i = 0; i < BK_WAVES; ++i) tw[i] = 0;
+        uint8_t tw[BK_WAVES], tw4[2 * BK_WAVES];
+        for (int i = 0; i < BK_WAVES; ++i) tw[i] = tw4[2 * i] = tw4[2 * i + 1] = 0;
         for (int i = 0; i < BK_R; ++i) {
             uint8_t ss = 0;
             if (i < rows) {
@@ -141,11 +141,13 @@ int build_block_plan(scn_conv_s* c) {
                     ell_v[e] = float2{G.h_val0[j], has_v1 ? G.h_val1[j] : 0.f};
                 }
                 tw[i >> 3] = std::max<uint8_t>(tw[i >> 3], (uint8_t)((j1 - j0 + 1) & ~1));
+                tw4[i >> 2] = std::max<uint8_t>(tw4[i >> 2], (uint8_t)((j1 - j0 + 1) & ~1));
                 ss = has_id ? (uint8_t)local[r] : 0;
             }
             self_slot.push_back(ss);
         }
         tile_w.insert(tile_w.end(), tw, tw + BK_WAVES);
+        tile_w4.insert(tile_w4.end(), tw4, tw4 + 2 * BK_WAVES);
         total_src += (int64_t)cur.size();
         r0 += rows;
         ++bid;
@@ -161,6 +163,7 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, ell_ptr, &P.dev.ell_ptr)) != SCN_OK) return st;
     if ((st = upload(c, width, &P.dev.width)) != SCN_OK) return st;
     if ((st = upload(c, tile_w, &P.dev.tile_w)) != SCN_OK) return st;
+    if ((st = upload(c, tile_w4, &P.dev.tile_w4)) != SCN_OK) return st;
     if ((st = upload(c, ell_slot, &P.dev.ell_slot)) != SCN_OK) return st;
     std::vector<uint16_t> ell_enc(ell_slot.size());
     for (size_t i = 0; i < ell_slot.size(); ++i) ell_enc[i] = (uint16_t)((ell_slot[i] << 9) | ((ell_slot[i] & 3) << 5));   // slot*512 | slot part of swz32
@@ -830,10 +833,10 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                 sm.v[i] = P.ell_v[ep + i];
             }
             if (tid < BK_R) sm.self[tid] = P.self_slot[(size_t)b * BK_R + tid];
-            if (tid < BK_WAVES) tws[tid] = P.tile_w[b * BK_WAVES + tid];
+            if (tid < W16_WAVES) tws[tid] = P.tile_w4[b * W16_WAVES + tid];
         }
         __syncthreads();
-        const int tw = tws[wave >> 1];
+        const int tw = tws[wave];                    // width of this wave's own 4 rows
         const int rtc = rt < m.rows ? rt : m.rows - 1;
         uint32_t goff[NDMA];
         const int total = m.nsrc * CPP;
