@@ -73,7 +73,8 @@ class WorkList:
         At.sort_indices()
         nz = np.flatnonzero(np.diff(At.indptr) > 0)
         ptr = np.concatenate([[0], np.cumsum(np.diff(At.indptr)[nz])]).astype(np.int32)
-        to = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(device)
+        # (an empty list still needs valid pointers: pad the arrays with one unused element)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(np.append(a, 0), np.int32)).to(device)
         self.block, self.ptr, self.slab = to(nz), to(ptr), to(At.indices)
         self.n_work, self.items = int(len(nz)), int(At.nnz)
         self.desc = WorkListDesc(self.n_work, self.block.data_ptr(), self.ptr.data_ptr(), self.slab.data_ptr())
