@@ -17,6 +17,7 @@ P_f32 = ctypes.POINTER(c_f32)
 SCN_MAX_GROUPS = 3
 SCN_MAX_SLOTS = 4
 ACT = {"none": 0, "tanh": 1, "relu": 2, "leaky_relu": 3}
+SCN_ERR_UNSUPPORTED = -4          # include/scone_hip.h
 
 
 class WorkListDesc(ctypes.Structure):          # scn_work_list (device pointers)

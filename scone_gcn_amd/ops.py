@@ -202,7 +202,7 @@ class ConvOp:
         with _timed("conv_fwd c1->%d" % c_out):
             st = lib.scn_conv_forward_first(self.handle, S, ns, _dev(x), ptr_array([_dev(w).value for w in Ws]), c_out,
                                             ACT[act], _dev(out), _dev(y), wl.ref() if wl is not None else None, _stream())
-        if st == -4:                                   # SCN_ERR_UNSUPPORTED
+        if st == _lib.SCN_ERR_UNSUPPORTED:
             return None
         check(st, "scn_conv_forward_first")
         return out, y

@@ -212,3 +212,22 @@ def test_jld2_reader_on_reference_file_if_present():
     gld = np.load(os.path.join(GOLDEN, "buoy.npz"))
     assert np.array_equal(elist, gld["elist"]) and np.array_equal(tlist, gld["tlist"]) and len(trajs) == 339
     assert bd.strip_paths([[1, 2, 1, 3, 4, 3, 5]]) == [[1, 3, 5]]
+
+
+def test_work_list_layout_and_square_detection(cx):
+    """Host logic of the zero-skipping mode: the (block, slab) list structure handed to the kernels, and the S_upper == S_lower^2
+    test that routes Ebli to the composed plan."""
+    import scipy.sparse as sp
+    import torch
+    from scone_gcn_amd import ops
+    A = sp.csr_matrix(np.array([[0, 1, 0, 1, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 0]], np.int32))     # [slab, block]
+    wl = ops.WorkList(A, torch.device("cpu"))
+    assert wl.n_work == 2 and wl.items == 3
+    assert wl.block[:2].tolist() == [1, 3] and wl.ptr[:3].tolist() == [0, 1, 3] and wl.slab[:3].tolist() == [0, 0, 1]
+    empty = ops.WorkList(sp.csr_matrix((3, 5), dtype=np.int32), torch.device("cpu"))
+    assert empty.n_work == 0 and empty.items == 0 and empty.block.data_ptr() != 0
+    sc = SimplicialComplex(cx)
+    L1, L1sq = sc.ebli_shifts()
+    assert ops._is_square_of(L1sq, L1) and not ops._is_square_of(L1, L1sq)
+    lo, up = sc.scone_shifts()
+    assert not ops._is_square_of(up, lo)
