@@ -479,8 +479,9 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
                 for (int k = 0; k < SP_ITEMS; ++k) {
                     const int idx = threadIdx.x + k * SP_THREADS;
                     if (idx < pend_total) {
-                        *(f32x4*)(ya + pend_off + (size_t)idx * 4) = pa[k];
-                        if (DUAL) *(f32x4*)(yb + pend_off + (size_t)idx * 4) = pb[k];
+                        // non-temporal: the outputs would otherwise evict the halo rows neighbouring blocks are about to read
+                        __builtin_nontemporal_store(pa[k], (f32x4*)(ya + pend_off + (size_t)idx * 4));
+                        if (DUAL) __builtin_nontemporal_store(pb[k], (f32x4*)(yb + pend_off + (size_t)idx * 4));
                     }
                 }
             }
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
         for (int k = 0; k < SP_ITEMS; ++k) {
             const int idx = threadIdx.x + k * SP_THREADS;
             if (idx < pend_total) {
-                *(f32x4*)(ya + pend_off + (size_t)idx * 4) = pa[k];
-                if (DUAL) *(f32x4*)(yb + pend_off + (size_t)idx * 4) = pb[k];
+                __builtin_nontemporal_store(pa[k], (f32x4*)(ya + pend_off + (size_t)idx * 4));
+                if (DUAL) __builtin_nontemporal_store(pb[k], (f32x4*)(yb + pend_off + (size_t)idx * 4));
             }
         }
     }
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const 
                 f32x4 v = zs * w0 + zl * w1 + zu * w2;
                 v[0] = act_apply_fast(act, v[0]); v[1] = act_apply_fast(act, v[1]);
                 v[2] = act_apply_fast(act, v[2]); v[3] = act_apply_fast(act, v[3]);
-                *(f32x4*)(o + (size_t)idx * 4) = v;
+                __builtin_nontemporal_store(v, (f32x4*)(o + (size_t)idx * 4));   // streamed out: keep the L2 for the gathered input
             }
         }
     }
