@@ -417,6 +417,7 @@ __device__ __forceinline__ void block_range(int n_blocks, int& first, int& last,
 // ------------------------------------------------------------------------------------------------
 constexpr int SP_THREADS = 1024;
 constexpr int SP_ITEMS = 2;           // BK_R * 32 chunks / SP_THREADS
+constexpr int SP_SLAB_GROUP = 8;      // slabs a workgroup processes per visit of a block
 
 __device__ __forceinline__ void dma_stage_sp(const char* Xs, char* buf, const Smem& sm, int nsrc, int piece, int cpp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -440,14 +441,18 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
     const int piece = K * 4, cpp = K / 4;
     const Smem sm = carve(smem, piece);
     uint8_t* tws = (uint8_t*)(smem + smem_bytes(piece));           // [BK_WAVES] per-row-group widths
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
-    if (slab0 >= slab1) return;
+    int b0, b_end, b_stride;
+    block_range(P.n_blocks, b0, b_end, b_stride);
+    const int slab_lo = (int)((int64_t)blockIdx.y * n_slabs / gridDim.y), slab_hi = (int)((int64_t)(blockIdx.y + 1) * n_slabs / gridDim.y);
+    if (slab_lo >= slab_hi) return;
     f32x4 pa[SP_ITEMS], pb[SP_ITEMS];
     size_t pend_off = 0;
     int pend_total = -1;
-    for (; b < b_end; b += b_stride) {
+    // slab groups outside, blocks inside: all workgroups sweep their blocks for the same 8 slabs before moving on, which
+    // keeps more of the halo rows that neighbouring blocks share within reach of the caches (-4 % at |E| = 1M; 4 or 16
+    // slabs per group are worse, and so is giving a workgroup a contiguous block range)
+    for (int slab0 = slab_lo; slab0 < slab_hi; slab0 += SP_SLAB_GROUP)
+    for (int b = b0, slab1 = min(slab0 + SP_SLAB_GROUP, slab_hi); b < b_end; b += b_stride) {
         wait_all_and_barrier();
         BlockMeta m;
         {   // load_block with this kernel's thread count
