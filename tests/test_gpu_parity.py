@@ -448,6 +448,68 @@ def test_ebli_composed_plan_matches_fused_operator(cfg1, sc1, hidden):
         assert _maxdiff(a.cpu().numpy(), bb) <= 2e-5 * max(1.0, np.abs(bb).max())
 
 
+def test_full_size_properties_at_one_million_edges():
+    """Size-independent properties on the benchmark complex itself (|E| = 996 634, hidden 32), where the oracle is out of reach:
+    (1) the dual SpMM is linear, (2) with tanh the log-probabilities do not depend on edge orientation (-flip_edges,
+    TE:214-219, 242-244, 288-296), (3) the zero-skipping modes reproduce the dense gradient step, (4) a row of zeros in,
+    a row of zeros out: padding trajectories get the uniform-over-D log-probabilities of all-zero logits."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(g.calibrate_n_points(1_000_000))
+    sc = SimplicialComplex(cx)
+    E = cx.n_edges
+    assert abs(E - 1_000_000) < 20_000
+    N = 6                                                          # 2 slabs, the second one half padding
+    paths = g.generate_random_walks(cx, m=N, seed=11, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=3)
+    D = sc.max_degree
+    y = so.onehot_targets(choice, D)
+    shapes = so.weight_shapes(1, [(3, 32)] * 3, 1)
+    w = [torch.tensor(a, dtype=torch.float32, device="cuda") for a in _rand_weights(shapes, 0.12, 5)]
+    outs = {}
+    for flip in (False, True):
+        shifts, readout, flips = te.setup_from_complex(sc, "scone", flip_edges=flip)
+        outs[flip] = te.scone_func(w, *shifts, readout, last, te.apply_flips(flows, flips)).cpu().numpy()
+        if not flip:
+            plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+            # (1) linearity of [L_lo X, L_up X]
+            rs = np.random.RandomState(0)
+            xa = torch.from_numpy(rs.randn(1, E, 8).astype(np.float32)).cuda()
+            xb = torch.from_numpy(rs.randn(1, E, 8).astype(np.float32)).cuda()
+            ya, yb = plan.conv.spmm_dual(xa), plan.conv.spmm_dual(xb)
+            yc = plan.conv.spmm_dual(2.0 * xa - 3.0 * xb)
+            for i in range(2):
+                ref = 2.0 * ya[i].double() - 3.0 * yb[i].double()
+                assert float((yc[i].double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+            # (4) padding rows: all-zero flow -> all-zero logits -> log(1/D) in every slot
+            x, n = ops.flows_to_slabs(flows, sc.layout, ops.default_device())
+            ld = ops._last_nodes_dev(last, x.shape[0] * ops.NS, ops.default_device())
+            logp, _ = plan.forward(x, ld, w)
+            assert float((logp[n:] + np.log(D)).abs().max()) <= 1e-6
+            # (3) zero-skipping == dense on a gradient step
+            inputs = [readout, last, flows]
+            grads = {}
+            for mode in ("dense", "zeros", "field"):
+                stm.reseed(1030)
+                net = stm.Scone_GCN(1, 1e-3, N, 5e-5, verbose=False, skip_mode=mode)
+                net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+                for a, b in zip(net.weights, w):
+                    a.copy_(b)
+                staged = net.stage(inputs, y, np.arange(N))
+                loss = float(net.grad_step_staged(inputs, staged, N, apply=False))
+                grads[mode] = (loss, [t.clone() for t in net._grads])
+            for mode in ("zeros", "field"):
+                assert abs(grads[mode][0] - grads["dense"][0]) <= 1e-6 * max(1.0, abs(grads["dense"][0]))
+                for a, b in zip(grads[mode][1], grads["dense"][1]):
+                    bb = b.cpu().numpy().astype(np.float64)
+                    assert _maxdiff(a.cpu().numpy(), bb) <= 2e-5 * max(1.0, np.abs(bb).max())
+    assert _maxdiff(outs[True], outs[False].astype(np.float64)) <= TOL      # (2)
+
+
 def test_errors_are_loud(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     shifts, readout, _ = te.setup_from_complex(sc1, "scone")
