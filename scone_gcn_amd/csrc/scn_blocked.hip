@@ -995,8 +995,10 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
                     const f32x4 dA1 = *(const f32x4*)(cur + eA.s1 * PIECE + swz16(eA.s1, chunk) * 16);
                     const f32x4 dB0 = *(const f32x4*)(cur + eB.s0 * PIECE + swz16(eB.s0, chunk) * 16);
                     const f32x4 dB1 = *(const f32x4*)(cur + eB.s1 * PIECE + swz16(eB.s1, chunk) * 16);
+                    __builtin_amdgcn_sched_barrier(0);      // all four reads (and the next pair's metadata) in flight before the FMAs
                     zlA += eA.v[0] * dA0; zuA += eA.v[1] * dA0; zlA += eA.v[2] * dA1; zuA += eA.v[3] * dA1;
                     zlB += eB.v[0] * dB0; zuB += eB.v[1] * dB0; zlB += eB.v[2] * dB1; zuB += eB.v[3] * dB1;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
@@ -1615,8 +1617,10 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
                     const f32x4 dA1 = *(const f32x4*)(cur + eA.s1 * PIECE + swz16(eA.s1, chunk) * 16);
                     const f32x4 dB0 = *(const f32x4*)(cur + eB.s0 * PIECE + swz16(eB.s0, chunk) * 16);
                     const f32x4 dB1 = *(const f32x4*)(cur + eB.s1 * PIECE + swz16(eB.s1, chunk) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
                     G[1][0] += eA.v[0] * dA0; G[2][0] += eA.v[1] * dA0; G[1][0] += eA.v[2] * dA1; G[2][0] += eA.v[3] * dA1;
                     G[1][1] += eB.v[0] * dB0; G[2][1] += eB.v[1] * dB0; G[1][1] += eB.v[2] * dB1; G[2][1] += eB.v[3] * dB1;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (dx) {
@@ -1973,11 +1977,20 @@ static void launch_grid(const scn_conv_s* c, int n_slabs, size_t lds, dim3& grid
     const int nb = c->plan.dev.n_blocks;
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int cap = 256 * per_cu;
-    int gx = std::min(cap, ((nb + 7) / 8) * 8);
-    gx = std::max(gx, 8);
-    int gy = 1;
-    if (gx < cap) gy = std::max(1, std::min(n_slabs, cap / gx));
-    grid = dim3(gx, gy);
+    // gx workgroups stride over the blocks (a multiple of 8: one share per XCD), gy split the slabs.  Pick the split whose
+    // busiest workgroup has the least (blocks x slabs) to do: at |E| = 50k (830 blocks) 256 x 1 leaves a 4-vs-3 block tail,
+    // 64 x 4 is even; at |E| = 1M the answer stays 256 x 1.
+    const int nb_xcd = (nb + 7) / 8;
+    long best = -1;
+    int bx = 8, by = 1;
+    for (int gy = 1; gy <= 32 && gy <= std::max(1, n_slabs); gy *= 2) {
+        int gx = std::max(8, std::min(cap / gy, ((nb + 7) / 8) * 8) / 8 * 8);
+        // a block visit costs its slabs plus about half a slab of prologue (ELL tile, DMA offsets)
+        const long work = (long)((nb_xcd + gx / 8 - 1) / (gx / 8)) * (2 * ((n_slabs + gy - 1) / gy) + 1);
+        const long cost = work * 64 + gy;                                                    // ties: fewer slab splits
+        if (best < 0 || cost < best) { best = cost; bx = gx; by = gy; }
+    }
+    grid = dim3(bx, by);
 }
 
 bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in, int c_out) {
