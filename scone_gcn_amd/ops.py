@@ -399,31 +399,31 @@ class SconePlan:
 
     # -- zero-skipping mode ---------------------------------------------------------------------------------
     def _block_graph(self):
+        """(block of row, row adjacency incl. self and transposes, rows -> blocks incidence, n_blocks)."""
         if self._blocks is None:
             import scipy.sparse as sp
             row0 = self.conv.plan_blocks()
             nb = len(row0) - 1
-            blk_of = (np.searchsorted(row0, np.arange(self.n_edges), side="right") - 1).astype(np.int64)
-            lo = self._pattern
-            coo = lo.tocoo()
-            adj = sp.csr_matrix((np.ones(coo.nnz, np.int32), (blk_of[coo.row], blk_of[coo.col])), shape=(nb, nb))
-            adj = ((adj + adj.T + sp.identity(nb, dtype=np.int32, format="csr")) > 0).astype(np.int32).tocsr()
-            self._blocks = (blk_of, adj, nb)
+            E = self.n_edges
+            blk_of = (np.searchsorted(row0, np.arange(E), side="right") - 1).astype(np.int64)
+            pat = (self._pattern != 0).astype(np.int32)
+            radj = ((pat + pat.T + sp.identity(E, dtype=np.int32, format="csr")) > 0).astype(np.int32).tocsr()
+            to_blk = sp.csr_matrix((np.ones(E, np.int32), (np.arange(E), blk_of)), shape=(E, nb))
+            self._blocks = (blk_of, radj, to_blk, nb)
         return self._blocks
 
-    def _readout_blocks(self):
-        """(n_nodes x n_blocks) 0/1: plan blocks holding an edge incident to a neighbour of the node (what Bcond(node) reads)."""
-        if getattr(self, "_ro_blocks", None) is None:
+    def _readout_rows(self):
+        """(n_nodes x n_edges) 0/1: device rows of the edges incident to a neighbour of the node (what Bcond(node) reads)."""
+        if getattr(self, "_ro_rows", None) is None:
             import scipy.sparse as sp
-            blk_of, _, nb = self._block_graph()
             V, D = self._h_nbr.shape
             r, c = np.nonzero(self._h_nbr >= 0)
             nbr = sp.csr_matrix((np.ones(len(r), np.int32), (r, self._h_nbr[r, c])), shape=(V, V))
             deg = np.diff(self._h_inc_ptr)
             inc = sp.csr_matrix((np.ones(len(self._h_inc_edge), np.int32),
-                                 (np.repeat(np.arange(V), deg), blk_of[self._h_inc_edge])), shape=(V, nb))
-            self._ro_blocks = ((nbr @ inc) > 0).astype(np.int32).tocsr()
-        return self._ro_blocks
+                                 (np.repeat(np.arange(V), deg), self._h_inc_edge)), shape=(V, self.n_edges))
+            self._ro_rows = ((nbr @ inc) > 0).astype(np.int32).tocsr()
+        return self._ro_rows
 
     def activity(self, flow, last_nodes, n_layers, hidden, mode):
         """Work lists of one micro-batch.  mode "zeros": every item whose value can be non-zero (a layer's output is
@@ -433,27 +433,34 @@ class SconePlan:
         import scipy.sparse as sp
         if mode in (None, "dense") or hidden != 32 or not self.conv.plan_info()[0]:
             return None
-        blk_of, adj, nb = self._block_graph()
+        blk_of, radj, to_blk, nb = self._block_graph()
         perm = self.layout.perm[1]
         flow = flow if isinstance(flow, SparseFlows) else SparseFlows.fromdense(np.asarray(flow))
         N = len(flow)
         S = pad_count(N, NS) // NS
+        E = self.n_edges
         traj = np.repeat(np.arange(N), np.diff(flow.ptr))
-        A = sp.csr_matrix((np.ones(len(traj), np.int32), (traj // NS, blk_of[perm[flow.idx]])), shape=(S, nb))
+        A = sp.csr_matrix((np.ones(len(traj), np.int32), (traj // NS, perm[flow.idx])), shape=(S, E))
         # rows the readout touches: edges incident to the neighbours of the last node (Bcond(last), TE:298-303)
         last = np.asarray(last_nodes)[:N]
         sel = sp.csr_matrix((np.ones(N, np.int32), (np.arange(N) // NS, last)), shape=(S, self.n_nodes))
-        R = sel @ self._readout_blocks()
-        hop = lambda M: ((M @ adj) > 0).astype(np.int32).tocsr()
-        sup = [(A > 0).astype(np.int32).tocsr()]
+        R = sel @ self._readout_rows()
+        # supports are tracked per ROW (one hop = the operator's own pattern) and only then mapped to plan blocks
+        hop = lambda M: ((M @ radj) > 0).astype(np.int32).tocsr()
+        blocks = lambda M: ((M @ to_blk) > 0).astype(np.int32).tocsr()
+        rows = [(A > 0).astype(np.int32).tocsr()]
         for _ in range(n_layers):
-            sup.append(hop(sup[-1]))                         # support of H_1 .. H_L
-        need = [None] * (n_layers + 1)
-        need[n_layers] = (R > 0).astype(np.int32).tocsr()     # gradient support of layer l's pre-activation = field of view
+            rows.append(hop(rows[-1]))                       # row support of H_1 .. H_L
+        need_rows = [None] * (n_layers + 1)
+        need_rows[n_layers] = (R > 0).astype(np.int32).tocsr()    # gradient support of layer l's pre-activation = field of view
         for l in range(n_layers - 1, 0, -1):
-            need[l] = hop(need[l + 1])
+            need_rows[l] = hop(need_rows[l + 1])
+        sup = [None] + [blocks(rows[l]) for l in range(1, n_layers + 1)]
+        need = [None] + [blocks(need_rows[l]) for l in range(1, n_layers + 1)]
+        if mode == "field":
+            sup = [None] + [blocks(rows[l].multiply(need_rows[l])) for l in range(1, n_layers + 1)]
         dev = self.device
-        fwd = [WorkList(sup[l].multiply(need[l]) if mode == "field" else sup[l], dev) for l in range(1, n_layers + 1)]
+        fwd = [WorkList(sup[l], dev) for l in range(1, n_layers + 1)]
         bwd = [None] + [WorkList(need[l], dev) for l in range(1, n_layers + 1)]
         total = S * nb
         return {"fwd": fwd, "bwd": bwd, "mode": mode,
