@@ -935,7 +935,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
                                                                 const float* __restrict__ W1,
                                                                 const float* __restrict__ W2,
                                                                 float* __restrict__ out, int n_rows, int n_cols,
-                                                                int n_slabs, int act) {
+                                                                int n_slabs, int act, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 256;
     const Smem sm = carve(smem, PIECE);
@@ -949,28 +949,27 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
         Bw[1][s] = W1[(4 * g + s) * 16 + p];
         Bw[2][s] = W2[(4 * g + s) * 16 + p];
     }
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
-    if (slab0 >= slab1) return;
+    SCN_UNIT_RANGE();
+    if (!listed && slab0 >= slab1) return;
     const int chunk = n * 4 + g;
     // D layout: column = lane&15 (channel), row = 4*g + r (point): row-in-quad = g, trajectory = r
     const int prA = wave * 8 + g, prB = prA + 4;
     f32x4 pendA, pendB;
     float* pend_ptr = nullptr;
     int pend_rows = 0;
-    for (; b < b_end; b += b_stride) {
+    SCN_UNIT_BEGIN()
         wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
         __syncthreads();
         const int tw = P.tile_w[b * BK_WAVES + wave];
         const int rA = rtA < m.rows ? rtA : m.rows - 1, rB = rtB < m.rows ? rtB : m.rows - 1;
-        dma_stage<PIECE, 16>((const char*)X + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
-        for (int slab = slab0; slab < slab1; ++slab) {
-            const char* cur = sm.buf((slab - slab0) & 1);
+        dma_stage<PIECE, 16>((const char*)X + (size_t)SLAB_AT(0) * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        for (int it = 0; it < n_it; ++it) {
+            const int slab = SLAB_AT(it);
+            const char* cur = sm.buf(it & 1);
             wait_vm_and_barrier();
-            if (slab + 1 < slab1)
-                dma_stage<PIECE, 16>((const char*)X + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+            if (it + 1 < n_it)
+                dma_stage<PIECE, 16>((const char*)X + (size_t)SLAB_AT(it + 1) * n_cols * PIECE, sm.buf((it + 1) & 1), sm,
                                      m.nsrc);
             if (pend_ptr) {
 #pragma unroll
@@ -1543,7 +1542,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
                                                                 const float* __restrict__ W2,
                                                                 const float* __restrict__ aux, float* __restrict__ dx,
                                                                 float* __restrict__ partial, int n_rows, int n_cols,
-                                                                int n_slabs, int act) {
+                                                                int n_slabs, int act, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIECE = 256;
     const Smem sm = carve(smem, PIECE);
@@ -1561,43 +1560,42 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c16_kernel(PlanDev P, const
     f32x4 dWacc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) dWacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int b, b_end, b_stride;
-    block_range(P.n_blocks, b, b_end, b_stride);
-    SCN_SLAB_RANGE();
+    SCN_UNIT_RANGE();
     const int chunk = n * 4 + g4;
     const int prA = wave * 8 + g4, prB = prA + 4;       // D-layout rows: point 4*g4 + r -> row-in-quad g4, trajectory r
-    if (slab0 < slab1)
-    for (; b < b_end; b += b_stride) {
+    if (listed || slab0 < slab1)
+    SCN_UNIT_BEGIN()
         wait_all_and_barrier();
         const BlockMeta m = load_block(P, b, sm);
         __syncthreads();
         const int tw = P.tile_w[b * BK_WAVES + wave];
         const int rA = rtA < m.rows ? rtA : m.rows - 1, rB = rtB < m.rows ? rtB : m.rows - 1;
-        dma_stage<PIECE, 16>((const char*)DZ + (size_t)slab0 * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
+        dma_stage<PIECE, 16>((const char*)DZ + (size_t)SLAB_AT(0) * n_cols * PIECE, sm.buf(0), sm, m.nsrc);
         float nA[4], nB[4];                                  // aux of the next slab (fetched one slab ahead)
         {
-            const size_t tb = ((size_t)slab0 * n_rows + m.row0) * (BK_NS * 16) + p;
+            const size_t tb = ((size_t)SLAB_AT(0) * n_rows + m.row0) * (BK_NS * 16) + p;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 nA[r] = prA < m.rows ? aux[tb + (prA * BK_NS + r) * 16] : 0.f;
                 nB[r] = prB < m.rows ? aux[tb + (prB * BK_NS + r) * 16] : 0.f;
             }
         }
-        for (int slab = slab0; slab < slab1; ++slab) {
-            const char* cur = sm.buf((slab - slab0) & 1);
+        for (int it = 0; it < n_it; ++it) {
+            const int slab = SLAB_AT(it);
+            const char* cur = sm.buf(it & 1);
             const size_t tbase = ((size_t)slab * n_rows + m.row0) * (BK_NS * 16) + p;
             wait_vm_and_barrier();
             float aA[4], aB[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { aA[r] = nA[r]; aB[r] = nB[r]; }
-            if (slab + 1 < slab1) {
-                const size_t tb = tbase + (size_t)n_rows * (BK_NS * 16);
+            if (it + 1 < n_it) {
+                const size_t tb = ((size_t)SLAB_AT(it + 1) * n_rows + m.row0) * (BK_NS * 16) + p;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     nA[r] = prA < m.rows ? aux[tb + (prA * BK_NS + r) * 16] : 0.f;
                     nB[r] = prB < m.rows ? aux[tb + (prB * BK_NS + r) * 16] : 0.f;
                 }
-                dma_stage<PIECE, 16>((const char*)DZ + (size_t)(slab + 1) * n_cols * PIECE, sm.buf((slab + 1 - slab0) & 1), sm,
+                dma_stage<PIECE, 16>((const char*)DZ + (size_t)SLAB_AT(it + 1) * n_cols * PIECE, sm.buf((it + 1) & 1), sm,
                                      m.nsrc);
             }
             f32x4 G[3][2];
@@ -2043,12 +2041,12 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
             default: SCN_LAUNCH_FWD32(SCN_ACT_NONE); break;
         }
     } else if (ci == 16) {
-        if (wl.block) return SCN_ERR_UNSUPPORTED;
         const size_t lds = smem_bytes(256);
         SCN_ENSURE_LDS(fwd_c16_kernel, lds);
         launch_grid(c, n_slabs, lds, grid);
+        if (wl.block) grid.y = 1;
         hipLaunchKernelGGL(fwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
-                           n_slabs, act);
+                           n_slabs, act, wl);
     } else {
         const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
         launch_grid(c, n_slabs, lds, grid);
@@ -2117,12 +2115,13 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
                 default: SCN_LAUNCH_BWD32(SCN_ACT_NONE); break;
             }
         }
-    } else if (wl.block) {
-        return SCN_ERR_UNSUPPORTED;                                  // work lists: C = 32 kernels only
     } else if (c_aux == 16) {
+        if (wl.block) grid.y = 1;
         SCN_ENSURE_LDS(bwd_c16_kernel, lds);
         hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
-                           nc, n_slabs, act);
+                           nc, n_slabs, act, wl);
+    } else if (wl.block) {
+        return SCN_ERR_UNSUPPORTED;                                  // first layer with a list: scn_conv_dw_first
     } else if (cd == 32) {
         SCN_ENSURE_LDS(bwd_c1_kernel<32>, lds);
         hipLaunchKernelGGL(bwd_c1_kernel<32>, grid, dim3(SP_THREADS), lds, st, P, dz[0], aux, partial, nr, nc, n_slabs);

@@ -431,7 +431,7 @@ class SconePlan:
         can see (the readout reads H_L on the edges around the last nodes; each layer below needs one more hop).
         Block granularity, so both are supersets.  None when the shape is not served by the work-list kernels."""
         import scipy.sparse as sp
-        if mode in (None, "dense") or hidden != 32 or not self.conv.plan_info()[0]:
+        if mode in (None, "dense") or hidden not in (16, 32) or not self.conv.plan_info()[0]:
             return None
         blk_of, radj, to_blk, nb = self._block_graph()
         perm = self.layout.perm[1]

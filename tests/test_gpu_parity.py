@@ -377,8 +377,9 @@ def test_first_layer_fast_path_matches_generic_entry_points(cfg1, sc1, hidden):
             assert _maxdiff(a.cpu().numpy(), bb + 0.25) <= 2e-5 * max(1.0, np.abs(bb).max())
 
 
-@pytest.mark.parametrize("model,mode", [("scone", "zeros"), ("scone", "field")])   # ebli: L1^2 rows exceed the block plan
-def test_zero_skipping_modes_match_the_dense_step(model, mode):
+@pytest.mark.parametrize("model,mode,hidden", [("scone", "zeros", 32), ("scone", "field", 32), ("scone", "zeros", 16),
+                                               ("scone", "field", 16)])   # ebli: L1^2 rows exceed the block plan
+def test_zero_skipping_modes_match_the_dense_step(model, mode, hidden):
     """Work-list (zero-skipping) execution of a gradient step == the dense execution, on a complex large enough to have
     inactive blocks: same loss, same weight gradients (to rounding of the summation order), buffers all-zero afterwards."""
     _need_gpu()
@@ -398,7 +399,7 @@ def test_zero_skipping_modes_match_the_dense_step(model, mode):
     for m in ("dense", mode):
         stm.reseed(1030)
         net = stm.Scone_GCN(1, 1e-3, N, 5e-5, verbose=False, skip_mode=m)
-        net.setup(te.MODEL_FUNCS[model], [(3, 32)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type=model)
+        net.setup(te.MODEL_FUNCS[model], [(3, hidden)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type=model)
         for w in net.weights:                                  # larger weights than 0.01 randn: gradients well above noise
             w.mul_(20.0 if model == "scone" else 3.0)
         staged = net.stage(inputs, y, np.arange(N))
