@@ -29,14 +29,15 @@ def hyperparams(args=None):
     hp = {'model': 'scone', 'epochs': 1000, 'learning_rate': 0.001, 'weight_decay': 0.00005, 'batch_size': 100,
           'hidden_layers': [(3, 16), (3, 16), (3, 16)], 'describe': 1, 'reverse': 0, 'load_data': 1,
           'load_model': 0, 'markov': 0, 'model_name': 'model', 'regional': 0, 'flip_edges': 0,
-          'data_folder_suffix': 'working', 'multi_graph': '', 'holes': 1}
+          'data_folder_suffix': 'working', 'multi_graph': '', 'holes': 1,
+          'skip_mode': 'dense'}          # not in the reference: dense | zeros | field (exact zero-skipping, Scone_GCN)
     for i in range(len(args) - 1):
         if args[i] and args[i][0] == '-':
             name = args[i][1:]
             if name == 'hidden_layers':
                 nums = list(map(int, args[i + 1].split("_")))
                 hp['hidden_layers'] = [(nums[j], nums[j + 1]) for j in range(0, len(nums), 2)]
-            elif name in ['model_name', 'data_folder_suffix', 'multi_graph', 'model']:
+            elif name in ['model_name', 'data_folder_suffix', 'multi_graph', 'model', 'skip_mode']:
                 hp[name] = str(args[i + 1])
             else:
                 try:
@@ -182,7 +183,8 @@ def train_model(hp=None):
         data_setup(hops=(1, 2), load=hp['load_data'], folder_suffix=hp['data_folder_suffix'], hp=hp)
     (inputs_1hop, inputs_2hop), (y_1hop, y_2hop) = inputs_all, y_all
     in_axes = tuple(([None] * len(shifts)) + [None, None, 0, 0])          # TE:325
-    scone = Scone_GCN(hp['epochs'], hp['learning_rate'], hp['batch_size'], hp['weight_decay'])
+    scone = Scone_GCN(hp['epochs'], hp['learning_rate'], hp['batch_size'], hp['weight_decay'],
+                      skip_mode=hp.get('skip_mode', 'dense'))
     if hp['model'] not in MODEL_FUNCS:
         raise Exception('invalid model')                                   # TE:445
     model_func = MODEL_FUNCS[hp['model']]
