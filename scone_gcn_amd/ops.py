@@ -425,44 +425,70 @@ class SconePlan:
             self._ro_rows = ((nbr @ inc) > 0).astype(np.int32).tocsr()
         return self._ro_rows
 
-    def activity(self, flow, last_nodes, n_layers, hidden, mode):
-        """Work lists of one micro-batch.  mode "zeros": every item whose value can be non-zero (a layer's output is
-        exactly zero outside the one-hop closure of its input's support); mode "field": additionally only what the loss
-        can see (the readout reads H_L on the edges around the last nodes; each layer below needs one more hop).
-        Block granularity, so both are supersets.  None when the shape is not served by the work-list kernels."""
+    def _trajectory_supports(self, flow, last_nodes, n_layers):
+        """Per TRAJECTORY and layer l = 1..L, as 0/1 matrices (N x n_blocks): Z[l] blocks holding a row where H_l can be
+        non-zero, D[l] blocks holding a row the loss can see (support of the gradient of layer l's pre-activation), F[l]
+        blocks holding a row that is both.  Computed once per dataset (cached on the identity of the inputs): supports are
+        tracked per ROW -- one hop = the operator's own pattern -- and only then mapped to plan blocks."""
+        import scipy.sparse as sp
+        ln = np.asarray(last_nodes)
+        if isinstance(flow, SparseFlows):                    # identity + a content fingerprint (in-place edits must miss)
+            fp = (len(flow), int(flow.ptr[-1]), int(flow.idx.sum()), float(np.abs(flow.val).sum()))
+        else:
+            fa = np.asarray(flow)
+            fp = (fa.shape, float(np.abs(fa.reshape(-1)[::max(1, fa.size // 65536)]).sum()))
+        key = (id(flow), id(last_nodes), n_layers, fp, int(ln.sum()), int(ln[:64].dot(np.arange(len(ln[:64])))))
+        c = getattr(self, "_act_cache", None)
+        if c is not None and c["key"] == key:
+            return c
+        blk_of, radj, to_blk, nb = self._block_graph()
+        perm = self.layout.perm[1]
+        fl = flow if isinstance(flow, SparseFlows) else SparseFlows.fromdense(np.asarray(flow))
+        N, E = len(fl), self.n_edges
+
+        def ones(M):                                         # 0/1 pattern of a product, in place
+            M = M.tocsr()
+            M.data[:] = 1
+            return M
+        hop = lambda M: ones(M @ radj)
+        blocks = lambda M: ones(M @ to_blk)
+        traj = np.repeat(np.arange(N), np.diff(fl.ptr))
+        rows = [ones(sp.csr_matrix((np.ones(len(traj), np.int32), (traj, perm[fl.idx])), shape=(N, E)))]
+        for _ in range(n_layers):
+            rows.append(hop(rows[-1]))                       # row support of H_1 .. H_L
+        # rows the readout touches: edges incident to the neighbours of the last node (Bcond(last), TE:298-303)
+        last = np.asarray(last_nodes)[:N]
+        sel = sp.csr_matrix((np.ones(N, np.int32), (np.arange(N), last)), shape=(N, self.n_nodes))
+        need = [None] * (n_layers + 1)
+        need[n_layers] = ones(sel @ self._readout_rows())
+        for l in range(n_layers - 1, 0, -1):
+            need[l] = hop(need[l + 1])
+        c = {"key": key, "keep": (flow, last_nodes), "N": N, "nb": nb,
+             "Z": [None] + [blocks(rows[l]) for l in range(1, n_layers + 1)],
+             "D": [None] + [blocks(need[l]) for l in range(1, n_layers + 1)],
+             "F": [None] + [blocks(rows[l].multiply(need[l])) for l in range(1, n_layers + 1)]}
+        self._act_cache = c
+        return c
+
+    def activity(self, flow, last_nodes, n_layers, hidden, mode, sel=None):
+        """Work lists of one micro-batch = trajectories `sel` (default: all) of the dataset (flow, last_nodes).
+        mode "zeros": every (block, slab) item that can hold a non-zero value (a layer's output is exactly zero outside the
+        one-hop closure of its input's support); mode "field": additionally only what the loss can see (the readout reads H_L
+        on the edges around the last nodes; each layer below needs one more hop).  None when the shape is not served by the
+        work-list kernels."""
         import scipy.sparse as sp
         if mode in (None, "dense") or hidden not in (16, 32) or not self.conv.plan_info()[0]:
             return None
-        blk_of, radj, to_blk, nb = self._block_graph()
-        perm = self.layout.perm[1]
-        flow = flow if isinstance(flow, SparseFlows) else SparseFlows.fromdense(np.asarray(flow))
-        N = len(flow)
-        S = pad_count(N, NS) // NS
-        E = self.n_edges
-        traj = np.repeat(np.arange(N), np.diff(flow.ptr))
-        A = sp.csr_matrix((np.ones(len(traj), np.int32), (traj // NS, perm[flow.idx])), shape=(S, E))
-        # rows the readout touches: edges incident to the neighbours of the last node (Bcond(last), TE:298-303)
-        last = np.asarray(last_nodes)[:N]
-        sel = sp.csr_matrix((np.ones(N, np.int32), (np.arange(N) // NS, last)), shape=(S, self.n_nodes))
-        R = sel @ self._readout_rows()
-        # supports are tracked per ROW (one hop = the operator's own pattern) and only then mapped to plan blocks
-        hop = lambda M: ((M @ radj) > 0).astype(np.int32).tocsr()
-        blocks = lambda M: ((M @ to_blk) > 0).astype(np.int32).tocsr()
-        rows = [(A > 0).astype(np.int32).tocsr()]
-        for _ in range(n_layers):
-            rows.append(hop(rows[-1]))                       # row support of H_1 .. H_L
-        need_rows = [None] * (n_layers + 1)
-        need_rows[n_layers] = (R > 0).astype(np.int32).tocsr()    # gradient support of layer l's pre-activation = field of view
-        for l in range(n_layers - 1, 0, -1):
-            need_rows[l] = hop(need_rows[l + 1])
-        sup = [None] + [blocks(rows[l]) for l in range(1, n_layers + 1)]
-        need = [None] + [blocks(need_rows[l]) for l in range(1, n_layers + 1)]
-        if mode == "field":
-            sup = [None] + [blocks(rows[l].multiply(need_rows[l])) for l in range(1, n_layers + 1)]
+        c = self._trajectory_supports(flow, last_nodes, n_layers)
+        sel = np.arange(c["N"]) if sel is None else np.asarray(sel)
+        n = len(sel)
+        S = pad_count(n, NS) // NS
+        agg = sp.csr_matrix((np.ones(n, np.int32), (np.arange(n) // NS, sel)), shape=(S, c["N"]))   # slab <- its trajectories
         dev = self.device
-        fwd = [WorkList(sup[l], dev) for l in range(1, n_layers + 1)]
-        bwd = [None] + [WorkList(need[l], dev) for l in range(1, n_layers + 1)]
-        total = S * nb
+        fsrc = c["F"] if mode == "field" else c["Z"]
+        fwd = [WorkList(agg @ fsrc[l], dev) for l in range(1, n_layers + 1)]
+        bwd = [None] + [WorkList(agg @ c["D"][l], dev) for l in range(1, n_layers + 1)]
+        total = S * c["nb"]
         return {"fwd": fwd, "bwd": bwd, "mode": mode,
                 "active_fraction": {"fwd": [w.items / total for w in fwd], "bwd": [w.items / total for w in bwd[1:]]}}
 

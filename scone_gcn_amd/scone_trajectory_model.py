@@ -205,7 +205,7 @@ class Scone_GCN():
             yt[:n] = torch.as_tensor(np.asarray(y)[sel], dtype=torch.float32).reshape(n, -1).to(device)
             activity = None
             if skip not in (None, "dense") and self.model_type != 'bunch':
-                activity = plan.activity(sub[2], np.asarray(sub[1]), len(self._shapes) // 3, self._shapes[0][1], skip)
+                activity = plan.activity(inputs[2], inputs[1], len(self._shapes) // 3, self._shapes[0][1], skip, sel=sel)
             staged.append((x, last_dev, yt, activity))
         return staged
 

@@ -14,6 +14,9 @@ net = stm.Scone_GCN(1, 1e-3, B, 5e-5, verbose=False, skip_mode="field")
 net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(B, int), model_type="scone")
 t0 = time.perf_counter(); staged = net.stage(inputs, y, np.arange(B)); print("stage %.3f s" % (time.perf_counter() - t0))
 t0 = time.perf_counter(); staged = net.stage(inputs, y, np.arange(B)); print("stage again %.3f s" % (time.perf_counter() - t0))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(3): net.stage(inputs, y, np.arange(B))
+pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 for _ in range(3): net.grad_step_staged(inputs, staged, B)
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
