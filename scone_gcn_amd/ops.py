@@ -496,6 +496,14 @@ class SconePlan:
         pool = self._zero_pool.setdefault(tuple(shape), [])
         return pool.pop() if pool else torch.zeros(tuple(shape), device=self.device, dtype=torch.float32)
 
+    def release(self, saved):
+        """Forward-only use of the zero-skipping mode (prediction): hand the forward's pooled buffers back, all-zero again."""
+        hs, bh, y0, activity = saved
+        if activity:
+            for l in range(1, len(hs)):
+                self._give_back(hs[l], activity["fwd"][l - 1])
+            self._give_back(y0, activity["fwd"][0])
+
     def _give_back(self, t, wl):
         self.conv.clear(t, wl)                              # all-zero again
         self._zero_pool.setdefault(tuple(t.shape), []).append(t)

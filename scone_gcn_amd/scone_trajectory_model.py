@@ -139,6 +139,17 @@ class Scone_GCN():
 
     def _predict(self, weights, inputs, idx=None):
         """log-probabilities (n, D, 1) for trajectories idx (all when None), no autograd."""
+        plan = self._plan(inputs) if (self.skip_mode != "dense" and self.model_type != 'bunch' and weights is self.weights) else None
+        if plan is not None:                            # zero-skipping forward (same log-probabilities, see SconePlan.activity)
+            idx_all = np.arange(_n_samples(inputs[-1])) if idx is None else np.asarray(idx)
+            staged = self.stage(inputs, np.zeros((_n_samples(inputs[-1]), plan.max_deg, 1), np.float32), idx_all)
+            if all(st[3] is not None for st in staged):
+                outs = []
+                for x, last_dev, _, activity in staged:
+                    logp, saved = plan.forward(x, last_dev, self.weights, activity)
+                    outs.append(logp.clone())
+                    plan.release(saved)
+                return torch.cat(outs)[:len(idx_all)].unsqueeze(-1)
         sub = inputs if idx is None else _select(inputs, idx)
         with torch.no_grad():
             return self.model(weights, *self.shifts, *sub)

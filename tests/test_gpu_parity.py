@@ -414,6 +414,13 @@ def test_zero_skipping_modes_match_the_dense_step(model, mode, hidden):
     for a, b in zip(res[mode][1], res["dense"][1]):
         bb = b.cpu().numpy().astype(np.float64)
         assert _maxdiff(a.cpu().numpy(), bb) <= 2e-5 * max(1.0, np.abs(bb).max())
+    # prediction path (forward only, buffers released without a backward): same loss and accuracy as the dense net
+    mask = np.ones(N, int)
+    n_nbrs = sc.n_nbrs(last)
+    l_skip = res[mode][3].loss(res[mode][3].weights, inputs, y, mask)
+    l_dense = res["dense"][3].loss(res["dense"][3].weights, inputs, y, mask)
+    assert abs(l_skip - l_dense) <= 1e-6 * max(1.0, abs(l_dense))
+    assert res[mode][3].accuracy(shifts, inputs, y, mask, n_nbrs) == res["dense"][3].accuracy(shifts, inputs, y, mask, n_nbrs)
     plan = res[mode][3]._plan(inputs)
     for pool in plan._zero_pool.values():
         for t in pool:
