@@ -717,10 +717,23 @@ class BunchPlan:
         cur = [torch.zeros((S, self.sizes[0], ns, 1), device=x.device), x,
                torch.zeros((S, self.sizes[2], ns, 1), device=x.device)]         # TE:179
         zero = [True, False, True]          # levels known to be identically zero (no bias terms: zeros stay zeros)
+        # only the node level of the last layer is read (TE:198-201): walk the seven shifts backwards to find which level
+        # outputs can reach it, and leave the others uncomputed (their gradient is identically zero as well)
+        L = int(n_layers)
+        need = [[False] * 3 for _ in range(L + 1)]
+        need[L][0] = True
+        for i in range(L - 1, 0, -1):
+            for k in range(7):
+                if need[i + 1][BUNCH_DST[k]]:
+                    need[i][BUNCH_SRC[k]] = True
         states, zeros = [cur], [zero]
-        for i in range(int(n_layers)):
+        for i in range(L):
             nxt, nzero = [], []
             for lvl in range(3):
+                if not need[i + 1][lvl]:
+                    nxt.append(None)
+                    nzero.append(True)          # nothing downstream that matters reads it: treated like a zero level
+                    continue
                 ks = [k for k in self.fwd_slots[lvl] if not zero[BUNCH_SRC[k]]]
                 c_out = weights[7 * i + self.fwd_slots[lvl][0]].shape[1]
                 if not ks:
