@@ -14,7 +14,7 @@ import scipy.sparse as sp
 from scipy.sparse.csgraph import reverse_cuthill_mckee
 
 from .bunch_model_matrices import compute_shift_matrices
-from .synthetic_data_gen import Complex, SparseFlows, incidence_matrices, neighborhood_table, complex_from_incidence
+from .synthetic_data_gen import Complex, incidence_matrices, neighborhood_table, complex_from_incidence
 
 
 def hilbert_index(x, y, order=16):

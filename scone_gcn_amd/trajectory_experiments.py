@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .complex import Bconds, Shift, SimplicialComplex
+from .complex import Bconds, SimplicialComplex
 from .synthetic_data_gen import SparseFlows
 
 MODEL_ACT = {"scone": "tanh", "ebli": "leaky_relu", "bunch": "relu"}

@@ -1,4 +1,4 @@
-import sys, numpy as np, torch
+import sys, numpy as np
 sys.path.insert(0, ".")
 from scone_gcn_amd import synthetic_data_gen as g, trajectory_experiments as te, scone_trajectory_model as stm
 from scone_gcn_amd.complex import SimplicialComplex

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: run fwd_c32 from the -DSCN_STAMPS build and print where a wave's cycles go per slab iteration."""
-import ctypes, os, sys, subprocess
+import ctypes, os, sys
 os.environ["SCN_LIB_PATH"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libscone_hip_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
