@@ -225,6 +225,13 @@ def main():
                           "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
                           "note": "same step, same results; work items whose values are exactly zero"
                                   + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
+        tf = os.path.join(ROOT, "profiles", "r01_skip_traffic.json")        # rocprofv3 --pmc passes of tools/pmc_skip.sh
+        if os.path.exists(tf) and E == 996634 and C == 32:
+            meas = json.load(open(tf))
+            skipping[mode]["hbm_bytes_per_trajectory"] = {
+                "dense_model": 4.0 * E * (15 * C + 2), "measured_dense": meas["dense"]["hbm_bytes_per_trajectory"],
+                "measured_this_mode": meas[mode]["hbm_bytes_per_trajectory"],
+                "source": "profiles/r01_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
         del st_m
 
     cpu = None
