@@ -184,6 +184,19 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
 
+/* Layers whose second shift is the square of the first (Ebli / SNN: S_lower = L1, S_upper = L1^2, TE:155-167, 251-253) on
+ * complexes where the rows of the square no longer fit the LDS-blocked plan.  `conv` holds S alone (identity + ONE value
+ * array); the caller forms y = S x (forward) or g1 = S^T dz (backward) with scn_spmm_dual and these calls do the rest:
+ *   forward :  out = act(x W[0] + y W[1] + (S y) W[2])                                    x0 = x, x = y below
+ *   backward:  dx = (dz W[0]^T + g1 W[1]^T + (S^T g1) W[2]^T) * act'(aux),  dW[k] += aux^T (dz | g1 | S^T g1)
+ * All tensors [n_slabs][n_rows][ns][channels]; served for channels = 32 (SCN_ERR_UNSUPPORTED / workspace 0 otherwise). */
+int scn_conv_forward_power(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x0, const float* x,
+                           const float* const* W, int32_t channels, int32_t act, float* out, void* stream);
+size_t scn_conv_backward_power_workspace(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t channels);
+int scn_conv_backward_power(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, const float* dz, const float* g1,
+                            const float* const* W, const float* aux, int32_t channels, int32_t act, float* dx,
+                            float* const* dW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Zero-skipping mode.  Activations of this path have no bias terms, so a layer's output is exactly zero wherever the
  * one-hop closure of its input's support does not reach; a trajectory batch on a large complex leaves most (block, slab)
  * work items all-zero.  A work list names the items that may be non-zero: listed plan blocks (scn_conv_plan_blocks gives

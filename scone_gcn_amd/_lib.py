@@ -73,6 +73,12 @@ SIGNATURES = {
     "scn_conv_forward_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_i32, c_i32,
                                               c_void_p, c_void_p, ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_conv_plan_blocks": (ctypes.c_int, [c_void_p, P_i32]),
+    "scn_conv_forward_power": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_i32,
+                                              c_i32, c_void_p, c_void_p]),
+    "scn_conv_backward_power_workspace": (c_size_t, [c_void_p, c_i32, c_i32, c_i32]),
+    "scn_conv_backward_power": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
+                                               c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+                                               c_size_t, c_void_p]),
     "scn_conv_forward_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
                                              ctypes.POINTER(c_void_p), c_i32, c_i32, c_void_p,
                                              ctypes.POINTER(WorkListDesc), c_void_p]),

@@ -293,7 +293,7 @@ __device__ __forceinline__ BlockMeta load_block_c32(const PlanDev& P, int b, con
 //    kernels are VALU-issue bound (profiles/r01_pmc_fwd_bwd_c32_bf16.txt), so instruction count is what matters;
 //  * all 2*NQ LDS reads of an entry pair are issued before the first FMA and the next pair's slots / values are fetched
 //    behind them: left to itself hipcc serialises read -> s_waitcnt lgkmcnt(0) -> use under register pressure.
-template <int NQ>
+template <int NQ, bool DUAL = true>     // DUAL = false: operator with one value array, gu is left untouched
 __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, const uint32_t (&cb)[NQ],
                                            f32x4 (&gs)[NQ], f32x4 (&gl)[NQ], f32x4 (&gu)[NQ]) {
     const char* lds = sm.buf0;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, in
         for (int q = 0; q < NQ; ++q) {
             gs[q] = *(const f32x4*)(lds + (cb[q] ^ enc));
             gl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DUAL) gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     for (int t = 0; t < tw; t += 2) {
@@ -326,12 +326,12 @@ __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, in
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             gl[q] += vc[0] * d0[q];
-            gu[q] += vc[1] * d0[q];
+            if (DUAL) gu[q] += vc[1] * d0[q];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             gl[q] += vc[2] * d1[q];
-            gu[q] += vc[3] * d1[q];
+            if (DUAL) gu[q] += vc[3] * d1[q];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -784,8 +784,12 @@ __device__ __forceinline__ f32x16 mfma_split(const Split3& w, const Split3& z, f
 constexpr int W16_THREADS = 1024, W16_WAVES = 16;
 constexpr int W16_WFRAG_BYTES = 3 * 2 * 3 * 64 * 16;      // [segment][co tile][split][lane] x 8 bf16
 
-template <int ACT>
+// EXT0: the operator has ONE value array and the layer is  act(X0 W0 + X W1 + (S X) W2)  -- segment 0 comes from a second
+// tensor X0 (the lane's own rows, straight from HBM), segment 1 is the staged tensor's own row, segment 2 its gathered shift
+// (Ebli on large complexes: X0 = H, X = S H, so the third term is S^2 H without ever forming S^2).
+template <int ACT, bool EXT0 = false>
 __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, const float* __restrict__ X,
+                                                                     const float* __restrict__ X0,
                                                                      const float* __restrict__ W0,
                                                                      const float* __restrict__ W1,
                                                                      const float* __restrict__ W2,
@@ -874,7 +878,15 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
             f32x4 z[3][2];                 // [segment][chunk q]: channels 8*kq + 4*q .. +3 of this lane's point
             {
                 const uint32_t cb[2] = {cqs[0] | (uint32_t)((it & 1) << 16), cqs[1] | (uint32_t)((it & 1) << 16)};
-                gather_c32<2>(sm, rtc, m.w, tw, cb, z[0], z[1], z[2]);
+                if (EXT0) {
+                    const float* x0 = X0 + (((size_t)slab * n_rows + m.row0 + rtc) * BK_NS + n) * 32 + 8 * kq;
+                    z[0][0] = *(const f32x4*)(x0);           // requested before the gather: its latency hides under it
+                    z[0][1] = *(const f32x4*)(x0 + 4);
+                    f32x4 unused[2];
+                    gather_c32<2, false>(sm, rtc, m.w, tw, cb, z[1], z[2], unused);
+                } else {
+                    gather_c32<2>(sm, rtc, m.w, tw, cb, z[0], z[1], z[2]);
+                }
             }
             STAMP_ADD(2);
             // MFMA: out^T tile (16 channels x 16 points) x 2 channel tiles; LDS-DMA of the next slab and the previous tile's
@@ -1321,8 +1333,11 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
 constexpr int B32_WFRAG_BYTES = 3 * 2 * 3 * 64 * 16;      // [segment][k-step][split][lane] x 8 bf16
 static_assert(B32_WFRAG_BYTES <= BK_WAVES * 16 * T32_STRIDE * 4, "weight fragments take the place of the fp32 kernel's patches");
 
-template <int ACT>
+// EXT0 (see fwd_c32_w16_kernel): segment 0 of G is the upstream gradient itself (DZ0, own rows from HBM), the staged tensor
+// DZ is S^T dz: segment 1 its own row, segment 2 its gathered shift (S^T)^2 dz.
+template <int ACT, bool EXT0 = false>
 __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, const float* __restrict__ DZ,
+                                                                     const float* __restrict__ DZ0,
                                                                      const float* __restrict__ W0,
                                                                      const float* __restrict__ W1,
                                                                      const float* __restrict__ W2,
@@ -1426,7 +1441,15 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             {
                 const uint32_t bufbit = (uint32_t)((it & 1) << 16);
                 const uint32_t cb[4] = {cqs[0] | bufbit, cqs[1] | bufbit, cqs[2] | bufbit, cqs[3] | bufbit};
-                gather_c32<4>(sm, rtc, m.w, tw, cb, G[0], G[1], G[2]);
+                if (EXT0) {
+                    const float* g0 = DZ0 + (((size_t)slab * n_rows + m.row0 + rtc) * BK_NS + n) * 32 + 16 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) G[0][q] = *(const f32x4*)(g0 + 4 * q);
+                    f32x4 unused[4];
+                    gather_c32<4, false>(sm, rtc, m.w, tw, cb, G[1], G[2], unused);
+                } else {
+                    gather_c32<4>(sm, rtc, m.w, tw, cb, G[0], G[1], G[2]);
+                }
             }
             STAMP_ADD(2);
             // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; the 8 LDS-DMA instructions of the next slab ride in
@@ -2022,8 +2045,8 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
 #define SCN_LAUNCH_FWD32W(A)                                                                                      \
     do {                                                                                                          \
         SCN_ENSURE_LDS(fwd_c32_w16_kernel<A>, lds16);                                                             \
-        hipLaunchKernelGGL(fwd_c32_w16_kernel<A>, grid, dim3(W16_THREADS), lds16, st, P, src[0], W[0], W[1], W[2], out, nr, \
-                           nc, n_slabs, wl);                                                                      \
+        hipLaunchKernelGGL(fwd_c32_w16_kernel<A>, grid, dim3(W16_THREADS), lds16, st, P, src[0], (const float*)nullptr,   \
+                           W[0], W[1], W[2], out, nr, nc, n_slabs, wl);                                           \
     } while (0)
             switch (act) {
                 case SCN_ACT_TANH: SCN_LAUNCH_FWD32W(SCN_ACT_TANH); break;
@@ -2105,8 +2128,8 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
 #define SCN_LAUNCH_BWD32(A)                                                                                       \
     do {                                                                                                          \
         SCN_ENSURE_LDS(bwd_c32_bf16_kernel<A>, lds);                                                              \
-        hipLaunchKernelGGL(bwd_c32_bf16_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, \
-                           partial, nr, nc, n_slabs, wl);                                                         \
+        hipLaunchKernelGGL(bwd_c32_bf16_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, dz[0], (const float*)nullptr,     \
+                           W[0], W[1], W[2], aux, dx, partial, nr, nc, n_slabs, wl);                              \
     } while (0)
             switch (act) {
                 case SCN_ACT_TANH: SCN_LAUNCH_BWD32(SCN_ACT_TANH); break;
@@ -2137,8 +2160,9 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     return SCN_OK;
 }
 
+// (with a y handed in the operator only supplies the row count and, for work lists, the block table)
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd) {
-    return scone_shape(c) && ns == BK_NS && (cd == 16 || cd == 32);
+    return c->plan.built && c->n_groups == 1 && ns == BK_NS && (cd == 16 || cd == 32);
 }
 
 static size_t dw_first_y_bytes(const scn_conv_s* c, int n_slabs) {
@@ -2171,6 +2195,7 @@ int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y,
         return SCN_OK;
     }
     if (!y) {
+        if (!scone_shape(c)) return SCN_ERR_UNSUPPORTED;          // recomputing y needs identity + two value arrays
         float* Y = (float*)ws;
         dim3 grid;
         const size_t lds = smem_bytes(16);
@@ -2195,6 +2220,71 @@ int blocked_clear_list(scn_conv_s* c, int ns, int ch, float* t, const WorkList* 
     if (wl->n_work == 0) return SCN_OK;
     hipLaunchKernelGGL(clear_list_kernel, dim3(std::min(wl->n_work, 2048)), dim3(256), 0, st, c->plan.dev, *wl, t, c->n_rows,
                        ns * ch);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+// ---- "power" layers: one operator S (identity + one value array), three terms  X0, S-input's own row, S * input ----
+static bool power_shape(const scn_conv_s* c) {
+    return c->plan.built && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 1;
+}
+bool blocked_power_supported(const scn_conv_s* c, int ns, int ch) { return power_shape(c) && ns == BK_NS && ch == 32; }
+
+size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch) {
+    if (!blocked_power_supported(c, ns, ch)) return 0;
+    dim3 grid;
+    launch_grid(c, n_slabs, smem_bytes_c32(B32_WFRAG_BYTES), grid);
+    return (size_t)grid.x * grid.y * 32 * 3 * 32 * sizeof(float);
+}
+
+int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const float* x, const float* const* W, int act,
+                          float* out, hipStream_t st) {
+    const PlanDev& P = c->plan.dev;
+    const WorkList wl{0, nullptr, nullptr, nullptr};
+    dim3 grid;
+    const size_t lds16 = smem_bytes_c32(W16_WFRAG_BYTES + 16);
+    launch_grid(c, n_slabs, lds16, grid);
+    const int nr = c->n_rows, nc = c->g[0].n_cols;
+#define SCN_LAUNCH_FWDP(A)                                                                                        \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS((fwd_c32_w16_kernel<A, true>), lds16);                                                     \
+        hipLaunchKernelGGL((fwd_c32_w16_kernel<A, true>), grid, dim3(W16_THREADS), lds16, st, P, x, x0, W[0], W[1], W[2], \
+                           out, nr, nc, n_slabs, wl);                                                             \
+    } while (0)
+    switch (act) {
+        case SCN_ACT_TANH: SCN_LAUNCH_FWDP(SCN_ACT_TANH); break;
+        case SCN_ACT_RELU: SCN_LAUNCH_FWDP(SCN_ACT_RELU); break;
+        case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_FWDP(SCN_ACT_LEAKY_RELU); break;
+        default: SCN_LAUNCH_FWDP(SCN_ACT_NONE); break;
+    }
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const float* g1, const float* const* W,
+                           const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st) {
+    const PlanDev& P = c->plan.dev;
+    const WorkList wl{0, nullptr, nullptr, nullptr};
+    dim3 grid;
+    const size_t lds = smem_bytes_c32(B32_WFRAG_BYTES);
+    launch_grid(c, n_slabs, lds, grid);
+    const int nr = c->n_rows, nc = c->g[0].n_cols;
+    float* partial = (float*)ws;
+#define SCN_LAUNCH_BWDP(A)                                                                                        \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS((bwd_c32_bf16_kernel<A, true>), lds);                                                      \
+        hipLaunchKernelGGL((bwd_c32_bf16_kernel<A, true>), grid, dim3(BK_THREADS), lds, st, P, g1, dz, W[0], W[1], W[2], \
+                           aux, dx, partial, nr, nc, n_slabs, wl);                                                \
+    } while (0)
+    switch (act) {
+        case SCN_ACT_TANH: SCN_LAUNCH_BWDP(SCN_ACT_TANH); break;
+        case SCN_ACT_RELU: SCN_LAUNCH_BWDP(SCN_ACT_RELU); break;
+        case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWDP(SCN_ACT_LEAKY_RELU); break;
+        default: SCN_LAUNCH_BWDP(SCN_ACT_NONE); break;
+    }
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blocked_dw_reduce, dim3((32 * 3 * 32 + 255) / 256), dim3(256), 0, st, partial, (int)(grid.x * grid.y), 32, 32,
+                       dW[0], dW[1], dW[2]);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -27,6 +27,12 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
                      float* const* dW, void* ws, size_t ws_bytes, const WorkList* wl, hipStream_t st);
 bool blocked_spmm_supported(const scn_conv_s* c, int k);
+bool blocked_power_supported(const scn_conv_s* c, int ns, int ch);
+size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
+int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const float* x, const float* const* W, int act,
+                          float* out, hipStream_t st);
+int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const float* g1, const float* const* W,
+                           const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
@@ -466,6 +472,31 @@ int scn_clear_list(scn_conv_t c, int32_t ns, int32_t channels, float* tensor, co
     if (!c || !tensor || !wl || !valid_list(wl) || channels <= 0) return SCN_ERR_BAD_ARG;
     WorkList wlist = to_list(wl);
     return blocked_clear_list(c, ns, channels, tensor, &wlist, (hipStream_t)stream);
+}
+
+int scn_conv_forward_power(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x0, const float* x,
+                           const float* const* W, int32_t channels, int32_t act, float* out, void* stream) {
+    if (!c || !x0 || !x || !W || !W[0] || !W[1] || !W[2] || !out) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (!blocked_power_supported(c, ns, channels)) return SCN_ERR_UNSUPPORTED;
+    return blocked_power_forward(c, n_slabs, x0, x, W, act, out, (hipStream_t)stream);
+}
+
+size_t scn_conv_backward_power_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, int32_t channels) {
+    if (!c || n_slabs <= 0) return 0;
+    const size_t b = blocked_power_backward_workspace(c, n_slabs, ns, channels);
+    return b ? b + 256 : 0;
+}
+
+int scn_conv_backward_power(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* dz, const float* g1,
+                            const float* const* W, const float* aux, int32_t channels, int32_t act, float* dx,
+                            float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !dz || !g1 || !W || !W[0] || !W[1] || !W[2] || !aux || !dW || !dW[0] || !dW[1] || !dW[2] || !workspace)
+        return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (!blocked_power_supported(c, ns, channels)) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < scn_conv_backward_power_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
+    return blocked_power_backward(c, n_slabs, dz, g1, W, aux, act, dx, dW, workspace, (hipStream_t)stream);
 }
 
 int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,

@@ -207,6 +207,36 @@ class ConvOp:
         check(st, "scn_conv_forward_first")
         return out, y
 
+    def forward_power(self, x0, x, Ws, act):
+        """out = act(x0 W0 + x W1 + (S x) W2) for an operator with identity + one value array (scn_conv_forward_power);
+        None when the shape is not served."""
+        lib = _lib.load()
+        S, rows, ns, c = x.shape
+        out = torch.empty_like(x)
+        with _timed("conv_fwd_power c%d" % c):
+            st = lib.scn_conv_forward_power(self.handle, S, ns, _dev(x0), _dev(x), ptr_array([_dev(w).value for w in Ws]), c,
+                                            ACT[act], _dev(out), _stream())
+        if st == _lib.SCN_ERR_UNSUPPORTED:
+            return None
+        check(st, "scn_conv_forward_power")
+        return out
+
+    def backward_power(self, dz, g1, Ws, aux, act, need_dx, dWs):
+        """Backward of forward_power given g1 = S^T dz (scn_conv_backward_power); returns (served, dx)."""
+        lib = _lib.load()
+        S, rows, ns, c = dz.shape
+        nbytes = int(lib.scn_conv_backward_power_workspace(self.handle, S, ns, c))
+        if nbytes == 0:
+            return False, None
+        ws = torch.empty(nbytes, device=dz.device, dtype=torch.uint8)
+        dx = torch.empty_like(aux) if need_dx else None
+        with _timed("conv_bwd_power c%d" % c):
+            check(lib.scn_conv_backward_power(self.handle, S, ns, _dev(dz), _dev(g1), ptr_array([_dev(w).value for w in Ws]),
+                                              _dev(aux), c, ACT[act], _dev(dx) if need_dx else None,
+                                              ptr_array([_dev(d).value for d in dWs]), ctypes.c_void_p(ws.data_ptr()),
+                                              ws.numel(), _stream()), "scn_conv_backward_power")
+        return True, dx
+
     def clear(self, t, wl):
         """Zero the listed items of a [S, rows, ns, C] tensor (scn_clear_list)."""
         check(_lib.load().scn_clear_list(self.handle, t.shape[2], t.shape[3], _dev(t), wl.ref(), _stream()), "scn_clear_list")
@@ -594,8 +624,9 @@ class PowerPlan(SconePlan):
         E = self.n_edges
         m = S_lower.device_csr()
         hint = self.layout.block_starts[S_lower.row_level]
-        self.op = ConvOp(E, [{"mats": [m], "identity": False, "n_cols": E}], hint)
-        self.op_T = self.op if S_lower.is_symmetric() else ConvOp(E, [{"mats": [m.T.tocsr()], "identity": False, "n_cols": E}], hint)
+        # identity slot on: the fused kernels read the staged tensor's own row as their middle term (the SpMM ignores it)
+        self.op = ConvOp(E, [{"mats": [m], "identity": True, "n_cols": E}], hint)
+        self.op_T = self.op if S_lower.is_symmetric() else ConvOp(E, [{"mats": [m.T.tocsr()], "identity": True, "n_cols": E}], hint)
         self.conv = self.conv_T = None
         self.nnz_pattern = self.nnz_lower = int(m.nnz)
         self.nnz_upper = int(S_upper.csr.nnz)
@@ -612,23 +643,37 @@ class PowerPlan(SconePlan):
     def conv_stack(self, x, weights, activity=None):
         n_layers = (len(weights) - 1) / 3
         assert n_layers % 1 == 0, "wrong number of weights"                    # TE:159-160
-        hs = [x]
+        hs, y0 = [x], None
         for i in range(int(n_layers)):
             w = weights[3 * i:3 * i + 3]
             g1 = self._shift(self.op, hs[-1])
-            g2 = self._shift(self.op, g1)
-            hs.append(dense_terms_forward([hs[-1], g1, g2], w, w[0].shape[1], self.act))
-        return hs, None
+            out = self.op.forward_power(hs[-1], g1, w, self.act) if hs[-1].shape[3] == w[0].shape[1] else None
+            if out is None:                            # widths the fused kernel does not take: shift again, dense terms
+                g2 = self._shift(self.op, g1)
+                out = dense_terms_forward([hs[-1], g1, g2], w, w[0].shape[1], self.act)
+                if i == 0 and x.shape[3] == 1:
+                    y0 = torch.cat([x, g1, g2], dim=3)  # the shifted input per point, for the first layer's weight gradient
+            hs.append(out)
+        return hs, y0
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
-        hs, bh, _, _ = saved
+        hs, bh, y0, _ = saved
         dz_top, key = self._readout_grad(hs[-1], bh, logp, d_logp, last_dev, weights, grads)
         L = len(hs) - 1
         dz = dz_top
         for i in reversed(range(L)):
-            g1 = self._shift(self.op_T, dz)
-            g2 = self._shift(self.op_T, g1)
-            dx = dense_terms_backward([dz, g1, g2], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0, grads[3 * i:3 * i + 3])
+            g1 = self._shift(self.op_T, dz) if not (i == 0 and y0 is not None) else None
+            served, dx = (self.op_T.backward_power(dz, g1, weights[3 * i:3 * i + 3], hs[i], self.act, i > 0,
+                                                   grads[3 * i:3 * i + 3])
+                          if (g1 is not None and hs[i].shape[3] == dz.shape[3]) else (False, None))
+            if not served and i == 0 and hs[0].shape[3] == 1 and y0 is not None \
+                    and self.op.dw_first(None, y0, dz, grads[0:3]):
+                dx = None                               # first layer: dW_k = sum_p (S^k x)[p] dz[p], one stream over dz
+            elif not served:
+                g1 = self._shift(self.op_T, dz) if g1 is None else g1
+                g2 = self._shift(self.op_T, g1)
+                dx = dense_terms_backward([dz, g1, g2], weights[3 * i:3 * i + 3], hs[i], self.act, i > 0,
+                                          grads[3 * i:3 * i + 3])
             if i == L - 1:
                 self._release_top(dz_top, key, last_dev)
             dz = dx
