@@ -73,3 +73,11 @@ def test_model_functions_refuse_to_run_without_a_gpu():
     from scone_gcn_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.default_device()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/scone_hip.h is the drop-in boundary: it has to compile as C99 without any C++ or HIP header."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "scone_hip.h"\nint main(void) { scn_work_list w = {0, 0, 0, 0}; (void)w; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "hdr.o")])
