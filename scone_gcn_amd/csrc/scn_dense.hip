@@ -295,6 +295,27 @@ __global__ __launch_bounds__(256) void dense_fwd_out1_kernel(DenseFwdArgs a) {
     }
 }
 
+// every term one channel wide (first layer of the composed Ebli / Bunch models): out[p][:] = act(sum_k g_k[p] * W_k[0][:]);
+// thread = (point, 4 output channels), weights in registers, coalesced 16-byte stores -- a pure write stream.
+__global__ __launch_bounds__(256) void dense_fwd_in1_kernel(DenseFwdArgs a) {
+    const int cg = a.c_out / 4;                                     // 256 % cg == 0 (c_out in {16, 32, 64})
+    const int cq = threadIdx.x % cg;
+    f32x4 w[DN_MAX_TERMS];
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k) w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t total = a.n_points * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pnt = i / cg;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) v += a.G[k][pnt] * w[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply_fast(a.act, v[j]);
+        __builtin_nontemporal_store(v, (f32x4*)(a.out + i * 4));
+    }
+}
+
 struct DenseReduceArgs {
     const float* partial;
     int32_t n_partials, total, n_terms;
@@ -345,6 +366,14 @@ int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* cons
             case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_LEAKY_RELU>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
             default: hipLaunchKernelGGL(dense_fwd_mfma_kernel<SCN_ACT_NONE>, dim3(blocks), dim3(DM_THREADS), 0, st, a); break;
         }
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
+    bool in1 = c_out == 16 || c_out == 32 || c_out == 64;
+    for (int k = 0; k < n_terms; ++k) in1 = in1 && c_in[k] == 1;
+    if (in1) {                                                      // one-channel terms
+        const int blocks = (int)std::min<int64_t>(8192, (n_points * (c_out / 4) + 255) / 256);
+        hipLaunchKernelGGL(dense_fwd_in1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         SCN_LAUNCH_CHECK();
         return SCN_OK;
     }

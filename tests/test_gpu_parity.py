@@ -269,7 +269,7 @@ def test_dense_terms_kernels_match_numpy():
     _need_gpu()
     from scone_gcn_amd import ops
     rs = np.random.RandomState(3)
-    for cs, c_out, c_aux, act in (([1, 1], 8, 1, "relu"), ([16, 16, 16], 16, 16, "relu"), ([32, 32], 32, 32, "tanh"),
+    for cs, c_out, c_aux, act in (([1, 1], 8, 1, "relu"), ([1, 1, 1], 32, 1, "leaky_relu"), ([1], 16, 1, "relu"), ([16, 16, 16], 16, 16, "relu"), ([32, 32], 32, 32, "tanh"),
                                   ([8, 8, 8], 1, 8, "none"), ([5, 3], 7, 5, "leaky_relu"), ([32, 32, 32], 1, 32, "relu"),
                                   ([16, 16], 1, 16, "relu"), ([32, 32, 32], 32, 32, "relu")):
         S, R, ns = 3, 157, 4
