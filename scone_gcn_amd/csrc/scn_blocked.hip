@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 #include "scn_internal.h"
 
@@ -101,7 +102,7 @@ int build_block_plan(scn_conv_s* c) {
     const bool has_v1 = G.n_vals > 1, has_id = G.identity == 1;
     const int n_rows = c->n_rows;
     std::vector<int32_t> blk_row0, src_ptr(1, 0), src_rows, ell_ptr;
-    std::vector<uint8_t> blk_rows, width, tile_w, tile_w4, ell_slot, self_slot;
+    std::vector<uint8_t> blk_rows, width, tile_w, tile_w4, tile_wu, tile_wu4, ell_slot, self_slot;
     std::vector<float2> ell_v;
     std::vector<int32_t> mark(G.n_cols, -1), local(G.n_cols, 0), cur;
     cur.reserve(BK_SRC + 64);
@@ -128,26 +129,36 @@ int build_block_plan(scn_conv_s* c) {
         const size_t base = ell_slot.size();                 // entries are [row][w], w even, zero padded
         ell_slot.resize(base + (size_t)w * rows, 0);
         ell_v.resize(base + (size_t)w * rows, float2{0.f, 0.f});
-        uint8_t tw[BK_WAVES], tw4[2 * BK_WAVES];
-        for (int i = 0; i < BK_WAVES; ++i) tw[i] = tw4[2 * i] = tw4[2 * i + 1] = 0;
+        uint8_t tw[BK_WAVES], tw4[2 * BK_WAVES], twu[BK_WAVES], twu4[2 * BK_WAVES];
+        for (int i = 0; i < BK_WAVES; ++i) tw[i] = tw4[2 * i] = tw4[2 * i + 1] = twu[i] = twu4[2 * i] = twu4[2 * i + 1] = 0;
         for (int i = 0; i < BK_R; ++i) {
             uint8_t ss = 0;
             if (i < rows) {
                 const int r = r0 + i;
                 const int j0 = G.h_rowptr[r], j1 = G.h_rowptr[r + 1];
-                for (int j = j0; j < j1; ++j) {
-                    const size_t e = base + (size_t)i * w + (j - j0);
-                    ell_slot[e] = (uint8_t)local[G.h_col[j]];
-                    ell_v[e] = float2{G.h_val0[j], has_v1 ? G.h_val1[j] : 0.f};
-                }
+                // entries the second operator takes part in come first, so the gather can stop feeding it after `twu`
+                int k = 0, n_up = 0;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int j = j0; j < j1; ++j) {
+                        const bool up = has_v1 && G.h_val1[j] != 0.f;
+                        if (up != (pass == 0)) continue;
+                        const size_t e = base + (size_t)i * w + k++;
+                        ell_slot[e] = (uint8_t)local[G.h_col[j]];
+                        ell_v[e] = float2{G.h_val0[j], has_v1 ? G.h_val1[j] : 0.f};
+                        n_up += up;
+                    }
                 tw[i >> 3] = std::max<uint8_t>(tw[i >> 3], (uint8_t)((j1 - j0 + 1) & ~1));
                 tw4[i >> 2] = std::max<uint8_t>(tw4[i >> 2], (uint8_t)((j1 - j0 + 1) & ~1));
+                twu[i >> 3] = std::max<uint8_t>(twu[i >> 3], (uint8_t)((n_up + 1) & ~1));
+                twu4[i >> 2] = std::max<uint8_t>(twu4[i >> 2], (uint8_t)((n_up + 1) & ~1));
                 ss = has_id ? (uint8_t)local[r] : 0;
             }
             self_slot.push_back(ss);
         }
         tile_w.insert(tile_w.end(), tw, tw + BK_WAVES);
         tile_w4.insert(tile_w4.end(), tw4, tw4 + 2 * BK_WAVES);
+        tile_wu.insert(tile_wu.end(), twu, twu + BK_WAVES);
+        tile_wu4.insert(tile_wu4.end(), twu4, twu4 + 2 * BK_WAVES);
         total_src += (int64_t)cur.size();
         r0 += rows;
         ++bid;
@@ -164,6 +175,8 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, width, &P.dev.width)) != SCN_OK) return st;
     if ((st = upload(c, tile_w, &P.dev.tile_w)) != SCN_OK) return st;
     if ((st = upload(c, tile_w4, &P.dev.tile_w4)) != SCN_OK) return st;
+    if ((st = upload(c, tile_wu, &P.dev.tile_wu)) != SCN_OK) return st;
+    if ((st = upload(c, tile_wu4, &P.dev.tile_wu4)) != SCN_OK) return st;
     if ((st = upload(c, ell_slot, &P.dev.ell_slot)) != SCN_OK) return st;
     std::vector<uint16_t> ell_enc(ell_slot.size());
     for (size_t i = 0; i < ell_slot.size(); ++i) ell_enc[i] = (uint16_t)((ell_slot[i] << 9) | ((ell_slot[i] & 3) << 5));   // slot*512 | slot part of swz32
@@ -294,7 +307,7 @@ __device__ __forceinline__ BlockMeta load_block_c32(const PlanDev& P, int b, con
 //  * all 2*NQ LDS reads of an entry pair are issued before the first FMA and the next pair's slots / values are fetched
 //    behind them: left to itself hipcc serialises read -> s_waitcnt lgkmcnt(0) -> use under register pressure.
 template <int NQ, bool DUAL = true>     // DUAL = false: operator with one value array, gu is left untouched
-__device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, const uint32_t (&cb)[NQ],
+__device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, int twu, const uint32_t (&cb)[NQ],
                                            f32x4 (&gs)[NQ], f32x4 (&gl)[NQ], f32x4 (&gu)[NQ]) {
     const char* lds = sm.buf0;
     const int rb = row * w;                                   // w is even: entry pairs are 4-byte aligned
@@ -310,7 +323,8 @@ __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, in
             if (DUAL) gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    for (int t = 0; t < tw; t += 2) {
+    // the plan puts the entries of the second operator first (its pattern is a subset): entries t >= twu only feed gl
+    auto pair = [&](int t, auto both) {
         const uint32_t e0 = ss & 0xffffu, e1 = ss >> 16;
         const f32x4 vc = v;
         f32x4 d0[NQ], d1[NQ];
@@ -326,15 +340,19 @@ __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, in
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             gl[q] += vc[0] * d0[q];
-            if (DUAL) gu[q] += vc[1] * d0[q];
+            if (decltype(both)::value) gu[q] += vc[1] * d0[q];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             gl[q] += vc[2] * d1[q];
-            if (DUAL) gu[q] += vc[3] * d1[q];
+            if (decltype(both)::value) gu[q] += vc[3] * d1[q];
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    int t = 0;
+    if (DUAL)
+        for (; t < twu; t += 2) pair(t, std::true_type{});
+    for (; t < tw; t += 2) pair(t, std::false_type{});
 }
 
 // LDS-DMA of nsrc pieces of slab-base Xs into buf: LDS image is lane-linear, the swizzle goes on the SOURCE chunk.
@@ -847,6 +865,7 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
         }
         __syncthreads();
         const int tw = tws[wave];                    // width of this wave's own 4 rows
+        const int twu = EXT0 ? 0 : P.tile_wu4[b * W16_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
         uint32_t goff[NDMA];
         const int total = m.nsrc * CPP;
@@ -883,9 +902,9 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                     z[0][0] = *(const f32x4*)(x0);           // requested before the gather: its latency hides under it
                     z[0][1] = *(const f32x4*)(x0 + 4);
                     f32x4 unused[2];
-                    gather_c32<2, false>(sm, rtc, m.w, tw, cb, z[1], z[2], unused);
+                    gather_c32<2, false>(sm, rtc, m.w, tw, 0, cb, z[1], z[2], unused);
                 } else {
-                    gather_c32<2>(sm, rtc, m.w, tw, cb, z[0], z[1], z[2]);
+                    gather_c32<2>(sm, rtc, m.w, tw, twu, cb, z[0], z[1], z[2]);
                 }
             }
             STAMP_ADD(2);
@@ -1394,6 +1413,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         const BlockMeta m = load_block_c32<BK_THREADS>(P, b, sm);
         __syncthreads();
         const int tw = P.tile_w[b * BK_WAVES + wave];
+        const int twu = EXT0 ? 0 : P.tile_wu[b * BK_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
         uint32_t goff[NDMA];
         const int total = m.nsrc * CPP;
@@ -1446,9 +1466,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) G[0][q] = *(const f32x4*)(g0 + 4 * q);
                     f32x4 unused[4];
-                    gather_c32<4, false>(sm, rtc, m.w, tw, cb, G[1], G[2], unused);
+                    gather_c32<4, false>(sm, rtc, m.w, tw, 0, cb, G[1], G[2], unused);
                 } else {
-                    gather_c32<4>(sm, rtc, m.w, tw, cb, G[0], G[1], G[2]);
+                    gather_c32<4>(sm, rtc, m.w, tw, twu, cb, G[0], G[1], G[2]);
                 }
             }
             STAMP_ADD(2);

@@ -96,6 +96,8 @@ struct PlanDev {
     const uint8_t* width;       // [n_blocks] padded entries per row
     const uint8_t* tile_w;      // [n_blocks][BK_WAVES] entries needed by each wave's 8 rows
     const uint8_t* tile_w4;     // [n_blocks][2*BK_WAVES] the same per 4 rows (16-wave kernels)
+    const uint8_t* tile_wu;     // [n_blocks][BK_WAVES] leading entries that carry a non-zero val1 (rows are ordered that way)
+    const uint8_t* tile_wu4;    // [n_blocks][2*BK_WAVES]
     const uint8_t* ell_slot;    // local slot of entry
     const uint16_t* ell_enc;    // the same for 512-byte pieces, ready to XOR into an LDS address: slot*512 | (slot&3)*32
     const float2* ell_v;        // (val0, val1) of entry
