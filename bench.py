@@ -31,8 +31,8 @@ HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--edges", type=int, default=1_000_000, help="target |E| of the synthetic complex")
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--per-gpu-batch", type=int, default=512)
