@@ -958,6 +958,176 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, C_in = C_out = 16, sixteen waves, exact bf16 three-way split -- the C=32 machinery on TWO slabs at a time:
+// a staged 512-byte piece is [slab A: 4 trajectories x 16 channels | slab B: the same], so the plan, the LDS image, the
+// XOR addressing and gather_c32 are shared with the C=32 kernels (the LDS-DMA takes a per-lane source address, which is
+// all the pairing needs).  wave = 4 rows; lane = (point = lane&15 -> row, trajectory n; channel quad g = lane>>4) holds
+// chunk q = the same point of slab A (q=0) and slab B (q=1): two 16-point MFMA tiles.
+//   per tile: v_mfma_f32_16x16x32_bf16 over K = [segment 0 | segment 1] (4 + 4 channels per lane) and
+//             v_mfma_f32_16x16x16_bf16 over segment 2, each as the six products of the split; weights stay in registers.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct Split3x4 { s16x4 hi, mid, lo; };
+__device__ __forceinline__ Split3x4 split3_4(const f32x4 x) {
+    uint32_t h[2], m[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        h[i] = pack_hi16(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        m[i] = pack_hi16(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        l[i] = pack_hi16(sa, sb);
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    Split3x4 s;
+    s.hi = __builtin_bit_cast(s16x4, u32x2{h[0], h[1]});
+    s.mid = __builtin_bit_cast(s16x4, u32x2{m[0], m[1]});
+    s.lo = __builtin_bit_cast(s16x4, u32x2{l[0], l[1]});
+    return s;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(W16_THREADS, 4) void fwd_c16_w16_kernel(PlanDev P, const float* __restrict__ X,
+                                                                     const float* __restrict__ W0,
+                                                                     const float* __restrict__ W1,
+                                                                     const float* __restrict__ W2,
+                                                                     float* __restrict__ out, int n_rows, int n_cols,
+                                                                     int n_slabs, WorkList wl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CPP = 32, NDMA = BK_SRC * CPP / W16_THREADS;   // 4 LDS-DMA instructions per wave and slab pair
+    const SmemC32 sm = carve_c32(smem);
+    uint8_t* tws = (uint8_t*)(smem + smem_bytes_c32());
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt = lane & 15, g = lane >> 4, n = pt & 3, rt = wave * 4 + (pt >> 2);
+    // A fragments: lane (out channel i = lane&15, k-group g): K=32 block = W0 rows 4g..4g+3 then W1 rows 4g..4g+3; K=16: W2
+    Split3 wa;
+    Split3x4 wb;
+    {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = W0[(4 * g + j) * 16 + pt];
+            w[4 + j] = W1[(4 * g + j) * 16 + pt];
+        }
+        wa = split3(w);
+        f32x4 w2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w2[j] = W2[(4 * g + j) * 16 + pt];
+        wb = split3_4(w2);
+    }
+    SCN_UNIT_RANGE();
+    if (!listed && slab0 >= slab1) return;
+    f32x4 pend[2];
+    float* pend_ptr[2] = {nullptr, nullptr};
+    // chunk of tile q inside a piece: q*16 + n*4 + g, swizzled like the DMA image (swz32: pos ^ bit 4 of the chunk ^ slot part)
+    uint32_t cqs[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cqs[q] = (uint32_t)((q * 16 + n * 4 + g) ^ q) << 4;
+    const size_t slab_bytes = (size_t)n_cols * 256;
+    SCN_UNIT_BEGIN()
+        wait_all_and_barrier();
+        BlockMeta m;
+        {
+            m.row0 = P.blk_row0[b];
+            m.rows = P.blk_rows[b];
+            const int sp0 = P.src_ptr[b];
+            m.nsrc = P.src_ptr[b + 1] - sp0;
+            m.w = P.width[b];
+            const int ep = P.ell_ptr[b];
+            for (int i = tid; i < m.nsrc; i += W16_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
+            for (int i = tid; i < m.w * m.rows; i += W16_THREADS) {
+                sm.enc[i] = P.ell_enc[ep + i];
+                sm.v[i] = P.ell_v[ep + i];
+            }
+            if (tid < BK_R) sm.self[tid] = P.self_slot[(size_t)b * BK_R + tid];
+            if (tid < W16_WAVES) tws[tid] = P.tile_w4[b * W16_WAVES + tid];
+        }
+        __syncthreads();
+        const int tw = tws[wave];
+        const int twu = P.tile_wu4[b * W16_WAVES + wave];
+        const int rtc = rt < m.rows ? rt : m.rows - 1;
+        uint32_t goff[NDMA];
+        bool second[NDMA];                            // this lane's chunk comes from slab B
+        const int total = m.nsrc * CPP;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int c = (i * W16_WAVES + wave) * 64 + lane;
+            const int slot = c / CPP, d = swz32(slot, c % CPP);
+            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * 256 + (d & 15) * 16 : 0u;
+            second[i] = (d >> 4) != 0;
+        }
+        auto dma = [&](int k, const char* XA, const char* XB, char* buf) {
+            const int base = (k * W16_WAVES + wave) * 64;
+            if (base + lane < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((second[k] ? XB : XA) + goff[k]),
+                                                 (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+        };
+        const int n_pairs = (n_it + 1) >> 1;
+        {
+            const char* XA = (const char*)X + (size_t)SLAB_AT(0) * slab_bytes;
+            const char* XB = n_it > 1 ? (const char*)X + (size_t)SLAB_AT(1) * slab_bytes : XA;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) dma(i, XA, XB, sm.buf(0));
+        }
+        for (int ip = 0; ip < n_pairs; ++ip) {
+            const bool has_b = 2 * ip + 1 < n_it;
+            const int slab_a = SLAB_AT(2 * ip), slab_b = has_b ? SLAB_AT(2 * ip + 1) : slab_a;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool more = ip + 1 < n_pairs;
+            const char* XnA = (const char*)X + (size_t)(more ? SLAB_AT(2 * ip + 2) : slab_a) * slab_bytes;
+            const char* XnB = (more && 2 * ip + 3 < n_it) ? (const char*)X + (size_t)SLAB_AT(2 * ip + 3) * slab_bytes : XnA;
+            char* nbuf = sm.buf((ip + 1) & 1);
+            f32x4 z[3][2];                 // [segment][tile q]: channels 4g..4g+3 of this lane's point in slab A / B
+            {
+                const uint32_t cb[2] = {cqs[0] | (uint32_t)((ip & 1) << 16), cqs[1] | (uint32_t)((ip & 1) << 16)};
+                gather_c32<2>(sm, rtc, m.w, tw, twu, cb, z[0], z[1], z[2]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)                        // the previous pair's results: a whole gather phase old by the
+                if (pend_ptr[q]) *(f32x4*)(pend_ptr[q]) = pend[q];   // time the next vmcnt(0) comes
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float x8[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x8[j] = z[0][q][j]; x8[4 + j] = z[1][q][j]; }
+                const Split3 za = split3(x8);
+                const Split3x4 zb = split3_4(z[2][q]);
+                // two accumulators: a chain of dependent MFMAs stays within one instruction shape
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acb = acc;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.lo, za.hi, acc, 0, 0, 0);     // small terms first
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.lo, zb.hi, acb, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.hi, za.lo, acc, 0, 0, 0);
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.hi, zb.lo, acb, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.mid, za.mid, acc, 0, 0, 0);
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.mid, zb.mid, acb, 0, 0, 0);
+                if (more) dma(2 * q, XnA, XnB, nbuf);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.mid, za.hi, acc, 0, 0, 0);
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.mid, zb.hi, acb, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.hi, za.mid, acc, 0, 0, 0);
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.hi, zb.mid, acb, 0, 0, 0);
+                if (more) dma(2 * q + 1, XnA, XnB, nbuf);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.hi, za.hi, acc, 0, 0, 0);
+                acb = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb.hi, zb.hi, acb, 0, 0, 0);
+                acc += acb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pend[q][r] = act_apply_fast(ACT, acc[r]);
+            }
+            // D: column = lane&15 = point, row = 4*g + r = output channel
+            const bool valid = rt < m.rows;
+            pend_ptr[0] = valid ? out + (((size_t)slab_a * n_rows + m.row0 + rt) * BK_NS + n) * 16 + 4 * g : nullptr;
+            pend_ptr[1] = valid && has_b ? out + (((size_t)slab_b * n_rows + m.row0 + rt) * BK_NS + n) * 16 + 4 * g : nullptr;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (pend_ptr[q]) *(f32x4*)(pend_ptr[q]) = pend[q];
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward, C_in = C_out = 16   (v_mfma_f32_16x16x4_f32; lane = (point p = lane&15, channel quad g = lane>>4);
 // a wave's 8 rows form two 16-point tiles (rows 0-3 / 4-7) with independent accumulators)
 // ------------------------------------------------------------------------------------------------
@@ -2084,6 +2254,26 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
             default: SCN_LAUNCH_FWD32(SCN_ACT_NONE); break;
         }
     } else if (ci == 16) {
+        static const bool f32_mfma16 = getenv("SCN_F32_MFMA") != nullptr;  // A/B switch: the 8-wave fp32-MFMA variant
+        if (!f32_mfma16) {                                                 // default: 16 waves, bf16x3, two slabs per visit
+            const size_t lds16 = smem_bytes_c32(16);
+            launch_grid(c, n_slabs, lds16, grid);
+            if (wl.block) grid.y = 1;
+#define SCN_LAUNCH_FWD16W(A)                                                                                      \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS(fwd_c16_w16_kernel<A>, lds16);                                                             \
+        hipLaunchKernelGGL(fwd_c16_w16_kernel<A>, grid, dim3(W16_THREADS), lds16, st, P, src[0], W[0], W[1], W[2], out, nr,  \
+                           nc, n_slabs, wl);                                                                      \
+    } while (0)
+            switch (act) {
+                case SCN_ACT_TANH: SCN_LAUNCH_FWD16W(SCN_ACT_TANH); break;
+                case SCN_ACT_RELU: SCN_LAUNCH_FWD16W(SCN_ACT_RELU); break;
+                case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_FWD16W(SCN_ACT_LEAKY_RELU); break;
+                default: SCN_LAUNCH_FWD16W(SCN_ACT_NONE); break;
+            }
+            SCN_LAUNCH_CHECK();
+            return SCN_OK;
+        }
         const size_t lds = smem_bytes(256);
         SCN_ENSURE_LDS(fwd_c16_kernel, lds);
         launch_grid(c, n_slabs, lds, grid);

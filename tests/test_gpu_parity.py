@@ -176,6 +176,26 @@ def test_spmm_dual_matches_scipy(cfg1, sc1):
             assert _maxdiff(yb[s].cpu().numpy(), up @ x[s].astype(np.float64)) <= 2e-5
 
 
+@pytest.mark.parametrize("hidden,slabs", [(16, 1), (16, 3), (16, 4), (32, 3)])
+def test_layer_forward_on_random_slabs_matches_scipy(cfg1, sc1, hidden, slabs):
+    """One layer act(X W0 + L_low X W1 + L_up X W2) (TE:145-147) through scn_conv_forward on dense random slabs -- the C=16
+    kernel works on PAIRS of slabs, so odd and single slab counts are the edge cases."""
+    from scone_gcn_amd import ops
+    shifts = sc1.scone_shifts()
+    plan = ops.get_scone_plan(shifts[0], shifts[1], sc1.bconds(), "tanh", ops.default_device())
+    rs = np.random.RandomState(3)
+    E, C = cfg1["E"], hidden
+    x = rs.randn(slabs, E, 4, C).astype(np.float32)
+    W = [(0.3 * rs.randn(C, C)).astype(np.float32) for _ in range(3)]
+    out = plan.conv.forward([torch.from_numpy(x).cuda()], [torch.from_numpy(w).cuda() for w in W], C, "tanh").cpu().numpy()
+    lo, up = shifts[0].device_csr(), shifts[1].device_csr()
+    for s in range(slabs):
+        xs = x[s].astype(np.float64).reshape(E, 4 * C)
+        ref = np.tanh(xs.reshape(E, 4, C) @ W[0].astype(np.float64) + (lo @ xs).reshape(E, 4, C) @ W[1].astype(np.float64)
+                      + (up @ xs).reshape(E, 4, C) @ W[2].astype(np.float64))
+        assert _maxdiff(out[s], ref) <= TOL
+
+
 def test_trainer_step_matches_oracle_adam(cfg1, sc1):
     """Scone_GCN.grad_step == oracle gradient + oracle Adam, for three consecutive steps on reference batches."""
     from scone_gcn_amd import trajectory_experiments as te
