@@ -1049,19 +1049,18 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c16_w16_kernel(PlanDev P, 
         const int twu = P.tile_wu4[b * W16_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
         uint32_t goff[NDMA];
-        bool second[NDMA];                            // this lane's chunk comes from slab B
+        const bool second = (lane >> 4) & 1;          // this lane's chunks come from slab B: bit 4 of d = bit 4 of pos = lane bit 4
         const int total = m.nsrc * CPP;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int c = (i * W16_WAVES + wave) * 64 + lane;
             const int slot = c / CPP, d = swz32(slot, c % CPP);
             goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * 256 + (d & 15) * 16 : 0u;
-            second[i] = (d >> 4) != 0;
         }
         auto dma = [&](int k, const char* XA, const char* XB, char* buf) {
             const int base = (k * W16_WAVES + wave) * 64;
             if (base + lane < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((second[k] ? XB : XA) + goff[k]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((second ? XB : XA) + goff[k]),
                                                  (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
         };
         const int n_pairs = (n_it + 1) >> 1;
@@ -1524,7 +1523,10 @@ static_assert(B32_WFRAG_BYTES <= BK_WAVES * 16 * T32_STRIDE * 4, "weight fragmen
 
 // EXT0 (see fwd_c32_w16_kernel): segment 0 of G is the upstream gradient itself (DZ0, own rows from HBM), the staged tensor
 // DZ is S^T dz: segment 1 its own row, segment 2 its gathered shift (S^T)^2 dz.
-template <int ACT, bool EXT0 = false>
+// PAIR: C = 16 on TWO slabs per visit -- the staged 512-byte piece is a point's 32 VIRTUAL channels (slab A's 16, slab B's 16:
+// the LDS-DMA's per-lane source address does the pairing), the weights are the block-diagonal diag(W, W), and aux / dx /
+// the weight-gradient blocks are addressed per slab; everything between is the C = 32 kernel as it stands.
+template <int ACT, bool EXT0 = false, bool PAIR = false>
 __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, const float* __restrict__ DZ,
                                                                      const float* __restrict__ DZ0,
                                                                      const float* __restrict__ W0,
@@ -1534,7 +1536,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                                                      float* __restrict__ dx, float* __restrict__ partial,
                                                                      int n_rows, int n_cols, int n_slabs, WorkList wl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!(EXT0 && PAIR), "the power form exists for C = 32 only");
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
+    constexpr int CH = PAIR ? 16 : 32;                       // channels of a stored point
     const SmemC32 sm = carve_c32(smem);
     char* wfrag = smem + smem_bytes_c32();
     const int lane = threadIdx.x & 63;
@@ -1547,7 +1551,10 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         const float* Wg = g == 0 ? W0 : (g == 1 ? W1 : W2);
         float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = Wg[(l & 31) * 32 + 16 * (l >> 5) + 8 * t + j];
+        for (int j = 0; j < 8; ++j) {
+            const int ca = l & 31, cc = 16 * (l >> 5) + 8 * t + j;
+            w[j] = !PAIR ? Wg[ca * 32 + cc] : ((ca >> 4) == (cc >> 4) ? Wg[(ca & 15) * 16 + (cc & 15)] : 0.f);
+        }
         const Split3 sp = split3(w);
         char* base = wfrag + ((g * 2 + t) * 3) * 1024 + l * 16;
         *(bf16x8*)(base) = sp.hi;
@@ -1576,7 +1583,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
     uint32_t cqs[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cqs[q] = (uint32_t)((n * 8 + h * 4 + q) ^ (n >> 1)) << 4;
-    const size_t slab_bytes = (size_t)n_cols * PIECE;
+    const size_t slab_bytes = (size_t)n_cols * (PAIR ? 256 : PIECE);
+    const bool second = PAIR && (((lane >> 2) ^ wave) & 1);       // this lane's LDS-DMA chunks come from slab B (see goff)
     if (listed || slab0 < slab1)
     SCN_UNIT_BEGIN()
         wait_all_and_barrier();
@@ -1591,22 +1599,34 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         for (int i = 0; i < NDMA; ++i) {
             const int c = (i * BK_WAVES + wave) * 64 + lane;
             const int slot = c / CPP, pos = c % CPP;
-            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * PIECE + swz32(slot, pos) * 16 : 0u;
+            const int d = swz32(slot, pos);                      // PAIR: virtual chunk n*8 + q*4 + g <- slab q, chunk n*4 + g;
+            goff[i] = c >= total ? 0u                            // q = bit 2 of d = ((lane>>2) ^ wave) & 1 for every i
+                      : (PAIR ? (uint32_t)sm.srcrows[slot] * 256 + ((d >> 3) * 4 + (d & 3)) * 16
+                              : (uint32_t)sm.srcrows[slot] * PIECE + d * 16);
         }
+        const int n_vis = PAIR ? (n_it + 1) >> 1 : n_it;          // visits: slabs, or slab pairs
+        auto slab_of = [&](int vis, int q) {                     // q-th slab of a visit (the lone last slab stands in for its pair)
+            if (!PAIR) return SLAB_AT(vis);
+            return SLAB_AT(2 * vis + q < n_it ? 2 * vis + q : 2 * vis);
+        };
+        auto src_base = [&](int vis) {
+            return (const char*)DZ + (size_t)slab_of(vis, second ? 1 : 0) * slab_bytes;
+        };
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int base = (i * BK_WAVES + wave) * 64;
             if (base + lane < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)DZ + (size_t)SLAB_AT(0) * slab_bytes + goff[i]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_base(0) + goff[i]),
                                                  (__attribute__((address_space(3))) void*)(sm.buf(0) + base * 16), 16, 0, 0);
         }
         const int rows_left = m.rows - wave * 8;
-        for (int it = 0; it < n_it; ++it) {
-            const int slab = SLAB_AT(it);
-            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * 32;
+        for (int it = 0; it < n_vis; ++it) {
+            const int slab = slab_of(it, PAIR ? p >> 4 : 0);      // PAIR: lanes p >= 16 hold slab B's channels
+            const bool lane_live = !PAIR || p < 16 || 2 * it + 1 < n_it;
+            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * CH;
             const float* ap = aux + (rows_left > 0 ? tuni : 0);
-            float* dp = dx ? dx + tuni : nullptr;
-            const int L0 = p + 128 * h;
+            float* dp = dx && lane_live ? dx + tuni : nullptr;
+            const int L0 = (PAIR ? p & 15 : p) + 4 * CH * h;
             STAMP_START();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP_ADD(0);
@@ -1619,8 +1639,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             float a[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = 2 * (r >> 2) + h < rows_left;
-                const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * 32 : 0];
+                const bool ok = 2 * (r >> 2) + h < rows_left && lane_live;
+                const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * CH : 0];
                 a[r] = ok ? v : 0.f;
             }
             bf16x8 wn[3];
@@ -1646,8 +1666,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             // the first four groups
             f32x16 acc = zero16;
             f32x16 T[3];
-            const bool more = it + 1 < n_it;
-            const char* Xn = (const char*)DZ + (size_t)(more ? SLAB_AT(it + 1) : slab) * slab_bytes;
+            const bool more = it + 1 < n_vis;
+            const char* Xn = src_base(more ? it + 1 : it);
             char* nbuf = sm.buf((it + 1) & 1);
             auto side = [&](int k) {
                 if (k < NDMA) {
@@ -1710,7 +1730,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     const Split3& at = At[t];
                     const int k0 = (g * 2 + t) * 3;                       // 18 store slots, 16 used
                     auto store = [&](int r) {
-                        if (dp && r < 16 && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+                        if (dp && r < 16 && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
                     };
                     dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bs.hi, dWacc[g], 0, 0, 0);
                     dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.lo, dWacc[g], 0, 0, 0);
@@ -1737,6 +1757,18 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             red[wave * 3072 + ca * 96 + g * 32 + p] = dWacc[g][r];
         }
     __syncthreads();
+    if (PAIR) {                                               // dW = the two diagonal blocks of the virtual 32x32 gradient
+        float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 768;
+        for (int i = threadIdx.x; i < 768; i += BK_THREADS) {
+            const int ca = i / 48, rem = i - ca * 48, g = rem >> 4, cc = rem & 15;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < BK_WAVES; ++w)
+                s += red[w * 3072 + ca * 96 + g * 32 + cc] + red[w * 3072 + (16 + ca) * 96 + g * 32 + 16 + cc];
+            outp[i] = s;
+        }
+        return;
+    }
     float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
     for (int i = threadIdx.x; i < 3072; i += BK_THREADS) {
         float s = 0.f;
@@ -2304,7 +2336,7 @@ bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz
 
 static size_t bwd_lds(int cd, int c_aux) {
     if (c_aux == 32) return smem_bytes_c32(B32_WFRAG_BYTES);   // (>= the fp32 variant's smem_bytes(512) + patches)
-    if (c_aux == 16) return smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4);
+    if (c_aux == 16) return std::max(smem_bytes_c32(B32_WFRAG_BYTES), smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4));
     return smem_bytes(BK_NS * cd * 4, 16);
 }
 
@@ -2349,10 +2381,26 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
             }
         }
     } else if (c_aux == 16) {
+        static const bool f32_mfma16 = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: the fp32-MFMA variant
         if (wl.block) grid.y = 1;
-        SCN_ENSURE_LDS(bwd_c16_kernel, lds);
-        hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial, nr,
-                           nc, n_slabs, act, wl);
+        if (f32_mfma16) {
+            SCN_ENSURE_LDS(bwd_c16_kernel, lds);
+            hipLaunchKernelGGL(bwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, dz[0], W[0], W[1], W[2], aux, dx, partial,
+                               nr, nc, n_slabs, act, wl);
+        } else {                                                            // default: the C=32 bf16x3 kernel on slab pairs
+#define SCN_LAUNCH_BWD16P(A)                                                                                      \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS((bwd_c32_bf16_kernel<A, false, true>), lds);                                               \
+        hipLaunchKernelGGL((bwd_c32_bf16_kernel<A, false, true>), grid, dim3(BK_THREADS), lds, st, P, dz[0],      \
+                           (const float*)nullptr, W[0], W[1], W[2], aux, dx, partial, nr, nc, n_slabs, wl);       \
+    } while (0)
+            switch (act) {
+                case SCN_ACT_TANH: SCN_LAUNCH_BWD16P(SCN_ACT_TANH); break;
+                case SCN_ACT_RELU: SCN_LAUNCH_BWD16P(SCN_ACT_RELU); break;
+                case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWD16P(SCN_ACT_LEAKY_RELU); break;
+                default: SCN_LAUNCH_BWD16P(SCN_ACT_NONE); break;
+            }
+        }
     } else if (wl.block) {
         return SCN_ERR_UNSUPPORTED;                                  // first layer with a list: scn_conv_dw_first
     } else if (cd == 32) {
