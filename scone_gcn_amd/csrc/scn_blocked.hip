@@ -35,7 +35,7 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP_DECL unsigned long long t0_ = 0, t1_ = 0, acc_[6] = {0, 0, 0, 0, 0, 0}
 #define STAMP_ADD(i) do { STAMP(t1_); acc_[i] += t1_ - t0_; t0_ = t1_; } while (0)
 #define STAMP_START() STAMP(t0_)
-#define STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_stamps[i_], acc_[i_]); atomicAdd(&g_stamps[7], 1ull); } } while (0)
+#define STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long s_ = 0; for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_stamps[i_], acc_[i_]); s_ += acc_[i_]; } atomicMax(&g_stamps[6], s_); atomicAdd(&g_stamps[7], 1ull); } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_ADD(i)

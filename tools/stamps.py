@@ -35,3 +35,4 @@ print("waves", waves, "slab iterations per wave %.0f" % iters)
 for i, n in enumerate(names):
     print("%-14s %6.1f %%   %8.0f cycles per iteration" % (n, 100.0 * buf[i] / tot, buf[i] / waves / iters))
 print("total per iteration %.0f cycles (memtime ticks)" % (tot / waves / iters))
+print("busiest wave / mean wave (stamped time over the whole launch): %.3f" % (buf[6] / (tot / waves)))
