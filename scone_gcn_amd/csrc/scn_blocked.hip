@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void fwd_c16_kernel(PlanDev P, const
 // then out = act(x*w0 + lo*w1 + up*w2) written as coalesced float4.
 // ------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(BK_THREADS, 2) void fwd_c1_kernel(PlanDev P, const float* __restrict__ X,
+__global__ __launch_bounds__(BK_THREADS, 6) void fwd_c1_kernel(PlanDev P, const float* __restrict__ X,
                                                                const float* __restrict__ W0,
                                                                const float* __restrict__ W1,
                                                                const float* __restrict__ W2,
@@ -2216,9 +2216,9 @@ static bool scone_shape(const scn_conv_s* c) {
 }
 
 // persistent grid: workgroups per CU by LDS footprint, blocks strided XCD-contiguously; small operators split slabs
-static void launch_grid(const scn_conv_s* c, int n_slabs, size_t lds, dim3& grid) {
+static void launch_grid(const scn_conv_s* c, int n_slabs, size_t lds, dim3& grid, int max_per_cu = 2) {
     const int nb = c->plan.dev.n_blocks;
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int per_cu = (max_per_cu >= 3 && lds <= 160 * 1024 / max_per_cu) ? max_per_cu : (lds <= 80 * 1024 ? 2 : 1);
     const int cap = 256 * per_cu;
     // gx workgroups stride over the blocks (a multiple of 8: one share per XCD), gy split the slabs.  Pick the split whose
     // busiest workgroup has the least (blocks x slabs) to do: at |E| = 50k (830 blocks) 256 x 1 leaves a 4-vs-3 block tail,
@@ -2314,7 +2314,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
                            n_slabs, act, wl);
     } else {
         const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
-        launch_grid(c, n_slabs, lds, grid);
+        launch_grid(c, n_slabs, lds, grid, 3);      // 8-wave workgroups at 64 VGPRs and 23 KB of LDS: three per CU (4.45 -> 3.9 ms; four: 4.8)
         if (wl.block) grid.y = 1;
         if (c_out == 32)
             hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
