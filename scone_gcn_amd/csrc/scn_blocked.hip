@@ -64,6 +64,8 @@ static int upload(scn_conv_s* c, const std::vector<T>& h, const T** out) {
     return SCN_OK;
 }
 
+int build_assignments(scn_conv_s* c);
+
 // Greedy block cut shared by the plan builder and scn_plan_refine_order: starting at row r0, take consecutive rows (< r_end)
 // while the block stays within BK_R rows, BK_SRC distinct source rows (the rows themselves included when the operator has
 // an identity slot) and BK_ELL_CAP padded ELL entries.  `mark` is a per-column stamp array (block id), `cur` gets the sources.
@@ -104,6 +106,7 @@ int build_block_plan(scn_conv_s* c) {
     std::vector<int32_t> blk_row0, src_ptr(1, 0), src_rows, ell_ptr;
     std::vector<uint8_t> blk_rows, width, tile_w, tile_w4, tile_wu, tile_wu4, ell_slot, self_slot;
     std::vector<float2> ell_v;
+    std::vector<float> block_gather;                              // per block: sum over the 8-row groups of their ELL width
     std::vector<int32_t> mark(G.n_cols, -1), local(G.n_cols, 0), cur;
     cur.reserve(BK_SRC + 64);
     int64_t total_src = 0;
@@ -157,6 +160,11 @@ int build_block_plan(scn_conv_s* c) {
         }
         tile_w.insert(tile_w.end(), tw, tw + BK_WAVES);
         tile_w4.insert(tile_w4.end(), tw4, tw4 + 2 * BK_WAVES);
+        {
+            float gather = 0.f;
+            for (int i = 0; i < BK_WAVES; ++i) gather += tw[i];
+            block_gather.push_back(gather);
+        }
         tile_wu.insert(tile_wu.end(), twu, twu + BK_WAVES);
         tile_wu4.insert(tile_wu4.end(), twu4, twu4 + 2 * BK_WAVES);
         total_src += (int64_t)cur.size();
@@ -184,10 +192,17 @@ int build_block_plan(scn_conv_s* c) {
     if ((st = upload(c, ell_v, &P.dev.ell_v)) != SCN_OK) return st;
     if ((st = upload(c, self_slot, &P.dev.self_slot)) != SCN_OK) return st;
     P.mean_src_per_row = (double)total_src / std::max(1, n_rows);
+    {   // one slab of a block costs a constant part (MFMA, epilogue, barriers: ~60 % on average, tools/stamps.py) + its gather
+        double mean = 0.0;
+        for (float g : block_gather) mean += g;
+        mean /= std::max<size_t>(1, block_gather.size());
+        P.h_cost.resize(block_gather.size());
+        for (size_t i = 0; i < block_gather.size(); ++i) P.h_cost[i] = (float)(1.5 * mean + block_gather[i]);
+    }
     P.h_row0 = blk_row0;
     P.h_row0.push_back(n_rows);
     P.built = true;
-    return SCN_OK;
+    return build_assignments(c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +437,7 @@ __device__ __forceinline__ void block_range(int n_blocks, int& first, int& last,
     SCN_SLAB_RANGE()
 #define SCN_UNIT_BEGIN()                                                             \
     for (; u_ < u_end_; u_ += u_stride_) {                                           \
-        const int b = listed ? wl.block[u_] : u_;                                    \
+        const int b = listed ? wl.block[u_] : (P.assign ? P.assign[u_] : u_);        \
         const int k0 = listed ? wl.ptr[u_] : slab0;                                  \
         const int n_it = listed ? wl.ptr[u_ + 1] - k0 : slab1 - slab0;               \
         if (n_it <= 0) continue;
@@ -470,7 +485,8 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
     // keeps more of the halo rows that neighbouring blocks share within reach of the caches (-4 % at |E| = 1M; 4 or 16
     // slabs per group are worse, and so is giving a workgroup a contiguous block range)
     for (int slab0 = slab_lo; slab0 < slab_hi; slab0 += SP_SLAB_GROUP)
-    for (int b = b0, slab1 = min(slab0 + SP_SLAB_GROUP, slab_hi); b < b_end; b += b_stride) {
+    for (int bi = b0, slab1 = min(slab0 + SP_SLAB_GROUP, slab_hi); bi < b_end; bi += b_stride) {
+        const int b = P.assign ? P.assign[bi] : bi;
         wait_all_and_barrier();
         BlockMeta m;
         {   // load_block with this kernel's thread count
@@ -2216,6 +2232,56 @@ static bool scone_shape(const scn_conv_s* c) {
 }
 
 // persistent grid: workgroups per CU by LDS footprint, blocks strided XCD-contiguously; small operators split slabs
+// Cost-balanced STATIC assignment of blocks to workgroups for a launch with gx workgroups per slab range: workgroup j of XCD
+// x visits positions b0 + j, b0 + j + stride, ... of its XCD's range (block_range); within every round of `stride` positions
+// the most expensive blocks go to the workgroups that have the least so far.  Blocks of a round still run at the same time
+// (halo rows stay shared in L2) and the assignment is fixed, so the weight gradient stays bitwise reproducible; the busiest
+// workgroup had 2.3 % (forward) / 3.4 % (backward) more than the mean with the plain stride.
+static const int32_t* balanced_assignment(const scn_conv_s* c, int gx) {   // tables are built with the plan, for every grid launch_grid can pick
+    static const bool off = getenv("SCN_NO_BALANCE") != nullptr;            // A/B switch: plain strided assignment
+    if (off) return nullptr;
+    auto it = c->plan.assign_by_grid.find(gx);
+    return it != c->plan.assign_by_grid.end() ? it->second : nullptr;
+}
+
+static int build_assignment(scn_conv_s* c, int gx) {
+    BlockPlan& B = c->plan;
+    const int nb = B.dev.n_blocks, stride = gx / 8;
+    if (stride <= 0 || nb <= gx || (int)B.h_cost.size() != nb || B.assign_by_grid.count(gx)) return SCN_OK;
+    std::vector<int32_t> assign(nb);
+    std::vector<double> load(stride);
+    std::vector<int> wg(stride), blk(stride);
+    for (int x = 0; x < 8; ++x) {
+        const int b0 = (int)((int64_t)nb * x / 8), last = (int)((int64_t)nb * (x + 1) / 8);
+        std::fill(load.begin(), load.end(), 0.0);
+        for (int r = b0; r < last; r += stride) {
+            const int cnt = std::min(stride, last - r);
+            for (int i = 0; i < cnt; ++i) { wg[i] = i; blk[i] = r + i; }
+            std::stable_sort(wg.begin(), wg.begin() + cnt, [&](int a, int b) { return load[a] < load[b]; });
+            std::stable_sort(blk.begin(), blk.begin() + cnt, [&](int a, int b) { return B.h_cost[a] > B.h_cost[b]; });
+            for (int i = 0; i < cnt; ++i) {
+                assign[r + wg[i]] = blk[i];
+                load[wg[i]] += B.h_cost[blk[i]];
+            }
+        }
+    }
+    const int32_t* dev = nullptr;
+    const int st = upload(c, assign, &dev);
+    if (st == SCN_OK) B.assign_by_grid[gx] = dev;
+    return st;
+}
+
+int build_assignments(scn_conv_s* c) {                      // every grid.x launch_grid can produce for this plan
+    const int nb = c->plan.dev.n_blocks;
+    for (int cap : {256, 512, 768})
+        for (int gy = 1; gy <= 32; gy *= 2) {
+            const int gx = std::max(8, std::min(cap / gy, ((nb + 7) / 8) * 8) / 8 * 8);
+            const int st = build_assignment(c, gx);
+            if (st != SCN_OK) return st;
+        }
+    return SCN_OK;
+}
+
 static void launch_grid(const scn_conv_s* c, int n_slabs, size_t lds, dim3& grid, int max_per_cu = 2) {
     const int nb = c->plan.dev.n_blocks;
     const int per_cu = (max_per_cu >= 3 && lds <= 160 * 1024 / max_per_cu) ? max_per_cu : (lds <= 80 * 1024 ? 2 : 1);
@@ -2245,7 +2311,7 @@ bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in,
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
                     const float* const* W, int c_out, int act, float* out, float* y_out, const WorkList* wlp,
                     hipStream_t st) {
-    const PlanDev& P = c->plan.dev;
+    PlanDev P = c->plan.dev;
     const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const int ci = c_in[0];
@@ -2257,6 +2323,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
         SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_RELU>, lds);
         SCN_ENSURE_LDS(fwd_c32_kernel<SCN_ACT_LEAKY_RELU>, lds);
         launch_grid(c, n_slabs, lds, grid);
+        P.assign = balanced_assignment(c, grid.x);
 #define SCN_LAUNCH_FWD32(A)                                                                                       \
     hipLaunchKernelGGL(fwd_c32_kernel<A>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc, \
                        n_slabs)
@@ -2290,6 +2357,7 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
         if (!f32_mfma16) {                                                 // default: 16 waves, bf16x3, two slabs per visit
             const size_t lds16 = smem_bytes_c32(16);
             launch_grid(c, n_slabs, lds16, grid);
+            P.assign = balanced_assignment(c, grid.x);
             if (wl.block) grid.y = 1;
 #define SCN_LAUNCH_FWD16W(A)                                                                                      \
     do {                                                                                                          \
@@ -2309,12 +2377,14 @@ int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src,
         const size_t lds = smem_bytes(256);
         SCN_ENSURE_LDS(fwd_c16_kernel, lds);
         launch_grid(c, n_slabs, lds, grid);
+        P.assign = balanced_assignment(c, grid.x);
         if (wl.block) grid.y = 1;
         hipLaunchKernelGGL(fwd_c16_kernel, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, nr, nc,
                            n_slabs, act, wl);
     } else {
         const size_t lds = smem_bytes(16, 2 * BK_R * BK_NS * 12);
         launch_grid(c, n_slabs, lds, grid, 3);      // 8-wave workgroups at 64 VGPRs and 23 KB of LDS: three per CU (4.45 -> 3.9 ms; four: 4.8)
+        P.assign = balanced_assignment(c, grid.x);
         if (wl.block) grid.y = 1;
         if (c_out == 32)
             hipLaunchKernelGGL(fwd_c1_kernel<32>, grid, dim3(BK_THREADS), lds, st, P, src[0], W[0], W[1], W[2], out, y_out, nr,
@@ -2351,7 +2421,7 @@ size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, cons
 int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
                      float* const* dW, void* ws, size_t ws_bytes, const WorkList* wlp, hipStream_t st) {
-    const PlanDev& P = c->plan.dev;
+    PlanDev P = c->plan.dev;
     const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const int cd = c_dz[0];
@@ -2359,6 +2429,7 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     float* partial = (float*)ws;
     const size_t lds = bwd_lds(cd, c_aux);
     launch_grid(c, n_slabs, lds, grid);
+    P.assign = balanced_assignment(c, grid.x);
     if (c_aux == 32) {
         static const bool f32_mfma = getenv("SCN_F32_MFMA") != nullptr;   // A/B switch: fp32-MFMA variant
         if (wl.block) grid.y = 1;
@@ -2497,11 +2568,12 @@ size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns
 
 int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const float* x, const float* const* W, int act,
                           float* out, hipStream_t st) {
-    const PlanDev& P = c->plan.dev;
+    PlanDev P = c->plan.dev;
     const WorkList wl{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const size_t lds16 = smem_bytes_c32(W16_WFRAG_BYTES + 16);
     launch_grid(c, n_slabs, lds16, grid);
+    P.assign = balanced_assignment(c, grid.x);
     const int nr = c->n_rows, nc = c->g[0].n_cols;
 #define SCN_LAUNCH_FWDP(A)                                                                                        \
     do {                                                                                                          \
@@ -2521,11 +2593,12 @@ int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const flo
 
 int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const float* g1, const float* const* W,
                            const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st) {
-    const PlanDev& P = c->plan.dev;
+    PlanDev P = c->plan.dev;
     const WorkList wl{0, nullptr, nullptr, nullptr};
     dim3 grid;
     const size_t lds = smem_bytes_c32(B32_WFRAG_BYTES);
     launch_grid(c, n_slabs, lds, grid);
+    P.assign = balanced_assignment(c, grid.x);
     const int nr = c->n_rows, nc = c->g[0].n_cols;
     float* partial = (float*)ws;
 #define SCN_LAUNCH_BWDP(A)                                                                                        \
@@ -2552,10 +2625,11 @@ bool blocked_spmm_supported(const scn_conv_s* c, int k) {
 }
 
 int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, float* yb, hipStream_t st) {
-    const PlanDev& P = c->plan.dev;
+    PlanDev P = c->plan.dev;
     dim3 grid;
     const size_t lds = smem_bytes(k * 4, 16);
     launch_grid(c, n_slabs, lds, grid);
+    P.assign = balanced_assignment(c, grid.x);
     SCN_ENSURE_LDS(spmm_blocked_kernel<true>, lds);
     SCN_ENSURE_LDS(spmm_blocked_kernel<false>, lds);
     if (yb)

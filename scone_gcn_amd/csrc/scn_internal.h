@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "scone_hip.h"
@@ -97,6 +98,7 @@ struct PlanDev {
     const uint8_t* tile_w;      // [n_blocks][BK_WAVES] entries needed by each wave's 8 rows
     const uint8_t* tile_w4;     // [n_blocks][2*BK_WAVES] the same per 4 rows (16-wave kernels)
     const uint8_t* tile_wu;     // [n_blocks][BK_WAVES] leading entries that carry a non-zero val1 (rows are ordered that way)
+    const int32_t* assign;      // optional [n_blocks]: visit position -> block (cost-balanced static assignment, per launch grid)
     const uint8_t* tile_wu4;    // [n_blocks][2*BK_WAVES]
     const uint8_t* ell_slot;    // local slot of entry
     const uint16_t* ell_enc;    // the same for 512-byte pieces, ready to XOR into an LDS address: slot*512 | (slot&3)*32
@@ -117,6 +119,8 @@ struct BlockPlan {
     PlanDev dev{};
     double mean_src_per_row = 0.0;
     std::vector<int32_t> h_row0;   // first row of every block (+ n_rows): scn_conv_plan_blocks
+    std::vector<float> h_cost;     // relative cost of one slab of every block (balanced_assignment)
+    std::map<int, const int32_t*> assign_by_grid;   // grid.x -> device table, built with the plan
     std::vector<void*> allocs;
 };
 
