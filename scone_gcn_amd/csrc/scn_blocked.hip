@@ -1674,7 +1674,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     f32x4 unused[4];
                     gather_c32<4, false>(sm, rtc, m.w, tw, 0, cb, G[1], G[2], unused);
                 } else {
+                    __builtin_amdgcn_s_setprio(3);
                     gather_c32<4>(sm, rtc, m.w, tw, twu, cb, G[0], G[1], G[2]);
+                    __builtin_amdgcn_s_setprio(1);
                 }
             }
             STAMP_ADD(2);
@@ -1722,6 +1724,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wh, acc, 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             STAMP_ADD(3);
             // dW A fragments from the aux tile (k-step t <-> points pt(8t + j, h)), then dX = acc * act'(aux)
             Split3 At[2];
