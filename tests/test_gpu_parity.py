@@ -252,8 +252,10 @@ def test_loss_accuracy_and_reverse_inputs(cfg1, sc1):
                - so.loss_from_preds(out_r, cfg1["rev_targets"][sel], mask, w, 5e-5)) <= TOL
 
 
-def test_larger_synthetic_complex_against_csr_oracle():
-    """E ~ 13k synthetic complex (own generator), hidden 32, oracle run with scipy CSR shifts."""
+@pytest.mark.parametrize("hidden,n_traj", [(32, 12), (16, 21)])
+def test_larger_synthetic_complex_against_csr_oracle(hidden, n_traj):
+    """E ~ 13k synthetic complex (own generator), oracle run with scipy CSR shifts.  Enough blocks for the launch grid to split
+    the slabs over several workgroup rows; at hidden 16 the slab-pair kernels see odd and partial slab ranges."""
     _need_gpu()
     import scipy.sparse as sp
     from scone_gcn_amd import synthetic_data_gen as g
@@ -261,11 +263,11 @@ def test_larger_synthetic_complex_against_csr_oracle():
     from scone_gcn_amd.complex import SimplicialComplex
     cx = g.random_SC_graph(5000)
     sc = SimplicialComplex(cx)
-    paths = g.generate_random_walks(cx, m=12, seed=5)
+    paths = g.generate_random_walks(cx, m=n_traj, seed=5)
     flows, choice, last, tnodes, _ = g.path_dataset(cx, paths, seed=2)
     D = sc.max_degree
     y = so.onehot_targets(choice, D)
-    shapes = so.weight_shapes(1, [(3, 32)] * 3, 1)
+    shapes = so.weight_shapes(1, [(3, hidden)] * 3, 1)
     w = _rand_weights(shapes, 0.15, 21)
     B1, B2 = g.incidence_matrices(cx)
     L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
