@@ -565,6 +565,120 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// dual SpMM, K = 128 or 64, as a RING of four half-piece stages: the staged unit is half a row piece (K/2 floats of every
+// source row), so the same 128 KB of LDS holds four stages instead of two buffers and three stages' LDS-DMAs are in flight
+// while one is consumed (the two-buffer kernel has one slab in flight at a time: DMA-only it runs 9.1 ms against 7.8 for
+// the traffic).  NI = LDS-DMA instructions per wave and stage (BK_SRC * K/8 chunks / 1024 lanes), issued
+// by EVERY wave with clamped source addresses so that `s_waitcnt vmcnt(NI * stages still in flight)` means the same thing in
+// every wave; loads complete in order among loads, so counting only them is safe with the result stores in between.
+// ------------------------------------------------------------------------------------------------
+constexpr int RING_SLAB_GROUP = 16;   // slabs per block visit: the ring's three-stage fill makes a visit dearer than in the two-buffer kernel (8: +1 %, 32: +1 %)
+
+template <int NI>
+__device__ __forceinline__ void wait_ring(int later) {           // `later` = stages issued after the one needed (wave-uniform)
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool DUAL, int NI>
+__global__ __launch_bounds__(SP_THREADS, 4) void spmm_ring_kernel(PlanDev P, const float* __restrict__ X,
+                                                                  float* __restrict__ ya, float* __restrict__ yb,
+                                                                  int n_rows, int n_cols, int n_slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 64 * NI, PIECE = K * 4, HALF = PIECE / 2, CPH = HALF / 16;     // chunks per half piece: 16 or 8
+    constexpr int STAGE = BK_SRC * HALF;                                             // 32 KB / 16 KB; 4 stages = both buffers
+    static_assert(BK_SRC * CPH == NI * SP_THREADS, "every lane issues exactly NI LDS-DMA chunks per stage");
+    const Smem sm = carve(smem, PIECE);
+    uint8_t* tws = (uint8_t*)(smem + smem_bytes(PIECE));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int b0, b_end, b_stride;
+    block_range(P.n_blocks, b0, b_end, b_stride);
+    const int slab_lo = (int)((int64_t)blockIdx.y * n_slabs / gridDim.y), slab_hi = (int)((int64_t)(blockIdx.y + 1) * n_slabs / gridDim.y);
+    if (slab_lo >= slab_hi) return;
+    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+    float *pend_a = nullptr, *pend_b = nullptr;
+    for (int slab0 = slab_lo; slab0 < slab_hi; slab0 += RING_SLAB_GROUP)
+    for (int bi = b0, slab1 = min(slab0 + RING_SLAB_GROUP, slab_hi); bi < b_end; bi += b_stride) {
+        const int b = P.assign ? P.assign[bi] : bi;
+        wait_all_and_barrier();
+        BlockMeta m;
+        {
+            m.row0 = P.blk_row0[b];
+            m.rows = P.blk_rows[b];
+            const int sp0 = P.src_ptr[b];
+            m.nsrc = P.src_ptr[b + 1] - sp0;
+            m.w = P.width[b];
+            const int ep = P.ell_ptr[b];
+            for (int i = threadIdx.x; i < m.nsrc; i += SP_THREADS) sm.srcrows[i] = P.src_rows[sp0 + i];
+            for (int i = threadIdx.x; i < m.w * m.rows; i += SP_THREADS) {
+                sm.slot[i] = P.ell_slot[ep + i];
+                sm.v[i] = P.ell_v[ep + i];
+            }
+            if (threadIdx.x < BK_WAVES) tws[threadIdx.x] = P.tile_w[b * BK_WAVES + threadIdx.x];
+        }
+        __syncthreads();
+        // this lane's NI chunks of a stage: chunk c = slot * CPH + pos, clamped into the block's sources
+        uint32_t goff[NI];
+        const int total = m.nsrc * CPH;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = min((i * (SP_THREADS / 64) + wave) * 64 + lane, total - 1);
+            goff[i] = (uint32_t)sm.srcrows[c / CPH] * PIECE + (c % CPH) * 16;
+        }
+        const int n_stage = 2 * (slab1 - slab0);
+        auto issue = [&](int q) {                                   // stage q = (slab slab0 + q/2, half q&1)
+            const char* src = (const char*)X + (size_t)(slab0 + (q >> 1)) * n_cols * PIECE + (q & 1) * HALF;
+            char* dst = sm.buf0 + (q & 3) * STAGE;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + goff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + ((i * (SP_THREADS / 64) + wave) * 64) * 16),
+                                                 16, 0, 0);
+        };
+        for (int q = 0; q < 3 && q < n_stage; ++q) issue(q);
+        // this thread's item of every stage: (row r, 16-byte chunk ch of the half piece)
+        const int idx = threadIdx.x, r = idx / CPH, ch = idx - r * CPH;
+        const bool live = r < m.rows;
+        const int tw = live ? __builtin_amdgcn_readfirstlane(tws[min(r, BK_R - 1) >> 3]) : 0;   // CPH >= 8: a wave's lanes share a row group
+        const int rb = r * m.w;
+        for (int q = 0; q < n_stage; ++q) {
+            wait_ring<NI>(min(n_stage - 1 - q, 2));
+            if (q + 3 < n_stage) issue(q + 3);
+            if (pend_a) {                                           // non-temporal, one stage late (see spmm_blocked_kernel)
+                __builtin_nontemporal_store(pa, (f32x4*)pend_a);
+                if (DUAL) __builtin_nontemporal_store(pb, (f32x4*)pend_b);
+            }
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            if (live) {
+                const char* cbase = sm.buf0 + (q & 3) * STAGE + ch * 16;
+#pragma unroll 2
+                for (int t = 0; t < tw; t += 2) {
+                    const EllPair e = ell_load(sm, rb + t);
+                    const f32x4 d0 = *(const f32x4*)(cbase + e.s0 * HALF);
+                    const f32x4 d1 = *(const f32x4*)(cbase + e.s1 * HALF);
+                    a0 += e.v[0] * d0;
+                    if (DUAL) a1 += e.v[1] * d0;
+                    a0 += e.v[2] * d1;
+                    if (DUAL) a1 += e.v[3] * d1;
+                }
+            }
+            pa = a0;
+            pb = a1;
+            const size_t off = ((size_t)(slab0 + (q >> 1)) * n_rows + m.row0 + r) * K + (q & 1) * (K / 2) + ch * 4;
+            pend_a = live ? ya + off : nullptr;
+            pend_b = live && DUAL ? yb + off : nullptr;
+        }
+    }
+    if (pend_a) {
+        __builtin_nontemporal_store(pa, (f32x4*)pend_a);
+        if (DUAL) __builtin_nontemporal_store(pb, (f32x4*)pend_b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward, C_in = C_out = 32   (v_mfma_f32_32x32x2_f32; lane = (point p = lane&31, channel half h = lane>>5))
 // (f32 MFMA and VALU do not overlap on a gfx950 SIMD -- tools/ubench/mfma_valu_overlap.hip -- so the waves are not
 // staggered; what does overlap with the MFMA chain is vector-memory issue, see c32_mfma_epilogue.)
@@ -2633,6 +2747,19 @@ int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, f
     const size_t lds = smem_bytes(k * 4, 16);
     launch_grid(c, n_slabs, lds, grid);
     P.assign = balanced_assignment(c, grid.x);
+    static const bool no_ring = getenv("SCN_SPMM_TWO_BUFFERS") != nullptr;      // A/B switch: the two-buffer kernel for every K
+    if (!no_ring && (k == 128 || k == 64)) {
+#define SCN_LAUNCH_RING(D, NI)                                                                                    \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS((spmm_ring_kernel<D, NI>), lds);                                                           \
+        hipLaunchKernelGGL((spmm_ring_kernel<D, NI>), grid, dim3(SP_THREADS), lds, st, P, x, ya, yb, c->n_rows,   \
+                           c->g[0].n_cols, n_slabs);                                                              \
+    } while (0)
+        if (yb) { if (k == 128) SCN_LAUNCH_RING(true, 2); else SCN_LAUNCH_RING(true, 1); }
+        else    { if (k == 128) SCN_LAUNCH_RING(false, 2); else SCN_LAUNCH_RING(false, 1); }
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
     SCN_ENSURE_LDS(spmm_blocked_kernel<true>, lds);
     SCN_ENSURE_LDS(spmm_blocked_kernel<false>, lds);
     if (yb)
