@@ -621,12 +621,15 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_ring_kernel(PlanDev P, con
         }
         __syncthreads();
         // this lane's NI chunks of a stage: chunk c = slot * CPH + pos, clamped into the block's sources
+        // (a block of rows without entries -- isolated nodes cluster in the holes of the complex -- has no sources at all:
+        // nothing is staged for it, its rows are written as zeros; has_src is uniform over the workgroup)
         uint32_t goff[NI];
+        const bool has_src = m.nsrc > 0;
         const int total = m.nsrc * CPH;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int c = min((i * (SP_THREADS / 64) + wave) * 64 + lane, total - 1);
-            goff[i] = (uint32_t)sm.srcrows[c / CPH] * PIECE + (c % CPH) * 16;
+            const int c = has_src ? min((i * (SP_THREADS / 64) + wave) * 64 + lane, total - 1) : 0;
+            goff[i] = has_src ? (uint32_t)sm.srcrows[c / CPH] * PIECE + (c % CPH) * 16 : 0u;
         }
         const int n_stage = 2 * (slab1 - slab0);
         auto issue = [&](int q) {                                   // stage q = (slab slab0 + q/2, half q&1)
@@ -638,7 +641,8 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_ring_kernel(PlanDev P, con
                                                  (__attribute__((address_space(3))) void*)(dst + ((i * (SP_THREADS / 64) + wave) * 64) * 16),
                                                  16, 0, 0);
         };
-        for (int q = 0; q < 3 && q < n_stage; ++q) issue(q);
+        if (has_src)
+            for (int q = 0; q < 3 && q < n_stage; ++q) issue(q);
         // this thread's item of every stage: (row r, 16-byte chunk ch of the half piece)
         const int idx = threadIdx.x, r = idx / CPH, ch = idx - r * CPH;
         const bool live = r < m.rows;
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_ring_kernel(PlanDev P, con
         const int rb = r * m.w;
         for (int q = 0; q < n_stage; ++q) {
             wait_ring<NI>(min(n_stage - 1 - q, 2));
-            if (q + 3 < n_stage) issue(q + 3);
+            if (has_src && q + 3 < n_stage) issue(q + 3);
             if (pend_a) {                                           // non-temporal, one stage late (see spmm_blocked_kernel)
                 __builtin_nontemporal_store(pa, (f32x4*)pend_a);
                 if (DUAL) __builtin_nontemporal_store(pb, (f32x4*)pend_b);

@@ -277,10 +277,19 @@ class ConvOp:
         return ya, yb
 
 
+def _pairable(widths, ns):
+    """All widths 16: two consecutive points are one 32-channel point under block-diagonal weights diag(W, W), which is the
+    shape the MFMA dense-term kernels take (the same trick as the paired C=16 convolution kernels)."""
+    return ns % 2 == 0 and all(int(c) == 16 for c in widths)
+
+
 def dense_terms_forward(Gs, Ws, c_out, act):
     """out[p,:] = act(sum_k G_k[p,:] @ W_k) over slab tensors [S, rows, ns, c_k] (scn_dense_terms_forward)."""
     lib = _lib.load()
     S, R, ns = Gs[0].shape[:3]
+    if _pairable([g.shape[3] for g in Gs] + [c_out], ns):
+        out = dense_terms_forward([g.view(S, R, ns // 2, 32) for g in Gs], [torch.block_diag(w, w) for w in Ws], 32, act)
+        return out.view(S, R, ns, 16)
     out = torch.empty((S, R, ns, c_out), device=Gs[0].device, dtype=torch.float32)
     with _timed("dense_fwd x%d ->%d" % (len(Gs), c_out)):
         check(lib.scn_dense_terms_forward(S * R * ns, len(Gs), ptr_array([_dev(g).value for g in Gs]),
@@ -292,6 +301,13 @@ def dense_terms_forward(Gs, Ws, c_out, act):
 def dense_terms_backward(Gs, Ws, aux, act, need_dx, dWs):
     lib = _lib.load()
     S, R, ns, c_aux = aux.shape
+    if _pairable([g.shape[3] for g in Gs] + [c_aux], ns):
+        wide = [torch.zeros((32, 32), device=aux.device, dtype=torch.float32) for _ in Gs]
+        dx = dense_terms_backward([g.view(S, R, ns // 2, 32) for g in Gs], [torch.block_diag(w, w) for w in Ws],
+                                  aux.view(S, R, ns // 2, 32), act, need_dx, wide)
+        for d, w in zip(dWs, wide):                       # the two diagonal blocks of the virtual 32x32 gradient
+            d.add_(w[:16, :16] + w[16:, 16:])
+        return dx.view(S, R, ns, 16) if need_dx else None
     cs = i32_array([g.shape[3] for g in Gs])
     n_points = S * R * ns
     nbytes = lib.scn_dense_terms_backward_workspace(n_points, len(Gs), cs, c_aux)

@@ -293,7 +293,8 @@ def test_dense_terms_kernels_match_numpy():
     rs = np.random.RandomState(3)
     for cs, c_out, c_aux, act in (([1, 1], 8, 1, "relu"), ([1, 1, 1], 32, 1, "leaky_relu"), ([1], 16, 1, "relu"), ([16, 16, 16], 16, 16, "relu"), ([32, 32], 32, 32, "tanh"),
                                   ([8, 8, 8], 1, 8, "none"), ([5, 3], 7, 5, "leaky_relu"), ([32, 32, 32], 1, 32, "relu"),
-                                  ([16, 16], 1, 16, "relu"), ([32, 32, 32], 32, 32, "relu")):
+                                  ([16, 16], 1, 16, "relu"), ([32, 32, 32], 32, 32, "relu"),
+                                  ([16, 16, 16], 16, 16, "relu"), ([16, 16], 16, 16, "tanh")):   # 16-wide: paired points, 32-wide kernels
         S, R, ns = 3, 157, 4
         Gs = [rs.randn(S, R, ns, c) for c in cs]
         Ws = [rs.randn(c, c_out) * 0.3 for c in cs]
@@ -332,6 +333,28 @@ def test_rectangular_single_operator_spmm(cfg1, sc1):
                 y, _ = op.spmm_dual(torch.from_numpy(x).cuda(), dual=False)
                 for s in range(2):
                     assert _maxdiff(y[s].cpu().numpy(), m @ x[s].astype(np.float64)) <= 2e-5
+
+
+def test_spmm_blocks_without_sources():
+    """Rows without entries (isolated nodes cluster inside the holes of a complex, SDG:98-114) form plan blocks with NO source
+    rows: nothing may be staged for them and their outputs are zeros.  K = 64 / 128 run the ring kernel, 100 the two-buffer one."""
+    _need_gpu()
+    import scipy.sparse as sp
+    from scone_gcn_amd import ops
+    rs = np.random.RandomState(4)
+    n_rows, n_cols = 700, 300
+    m = sp.random(n_rows, n_cols, density=0.02, random_state=rs, format="lil", dtype=np.float64)
+    m[:192] = 0                                            # the first three 64-row blocks are empty
+    m[400:530] = 0
+    m = m.tocsr(); m.eliminate_zeros()
+    op = ops.ConvOp(n_rows, [{"mats": [m], "identity": False, "n_cols": n_cols}])
+    for k in (64, 128, 100):
+        x = rs.randn(5, n_cols, k).astype(np.float32)
+        y, _ = op.spmm_dual(torch.from_numpy(x).cuda(), dual=False)
+        y = y.cpu().numpy()
+        for s_ in range(5):
+            assert _maxdiff(y[s_], m @ x[s_].astype(np.float64)) <= 2e-5
+        assert not y[:, :192].any() and not y[:, 400:530].any()
 
 
 def test_bunch_two_layers_larger_complex_against_csr_oracle():
