@@ -1,22 +1,39 @@
 #!/usr/bin/env python3
 """Headline benchmark: trajectories/sec, forward + backward (+ gradient all-reduce + Adam), 3-layer SCoNe.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3]): synthetic complex with |E| ~ 1M (370 000 points, the reference generator's
-recipe), hidden = 32, fp32, 512 trajectories per GPU per step (global batch 4096 at 8 GPUs -> weak scaling).
-A step = one optimiser step on one batch that is already resident in HBM: forward, loss, backward, RCCL all-reduce
-of the flat weight-gradient buffer, fused ridge + Adam.  Prints ONE JSON line on rank 0.
+With --gpus N > 1 and no launcher environment the script starts N fresh ranks itself through torch.distributed.run
+(before anything touches the GPU) and exits with their code; launched by `python -m torch.distributed.run ... bench.py
+--gpus N` it is one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  A rank count that
+differs from --gpus is an error, never a silent single-GPU run.
 
-Extra objects in the line:
-  roofline     -- the kernel family that takes the most time in the step, timed live with events on the launch
-                  stream: algorithmic bytes per launch / mean launch duration vs the 8 TB/s HBM peak.
-  cpu_baseline -- the CPU oracle (oracle/scone_oracle.py with scipy CSR shifts: a "port" of the reference
-                  formulation) timed on this box's host cores on a bounded sample of the same workload.
+Workload (BASELINE.json metric; configs[3]): synthetic complex with |E| ~ 1M (370 000 points, the reference
+generator's recipe), hidden = 32, fp32, GLOBAL batch 4096 sharded over the ranks (4096 / N trajectories per GPU ->
+strong scaling; at N = 1 one GPU runs all 4096 as 32 micro-batches of 128).  A step = one optimiser step on a batch
+that is already resident in HBM: forward, loss, backward, RCCL all-reduce of the flat weight-gradient buffer, fused
+ridge + Adam.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (N = 1 only, unless noted):
+  roofline      the kernel family that takes the most time in the step, timed live with events on the launch stream:
+                algorithmic bytes per launch / mean launch duration vs the 8 TB/s HBM peak; `dense_random` repeats the
+                two fused C=32 kernels on dense random tensors (the benchmark's activations are mostly exact zeros).
+  cpu_baseline  the reference formulation on this box's host cores: B2 = fp32 torch.sparse_csr forward + autograd
+                backward on a bounded sample of the SAME workload (oracle/torch_sparse.py), B1 = the dense-faithful fp32
+                torch restatement (dense shifts, full-N forward then mask, autograd, Adam; oracle/torch_dense.py) on
+                configs[0]; threads = torch.get_num_threads().
+  parity        loss + all ten weight gradients of the HIP step against the fp64 scipy-CSR oracle on trajectories of the
+                full-size complex.
+  configs       BASELINE.json configs[1] (|E|~50k, hidden 16, batch 1024), configs[2] (ocean drifters, full batch),
+                configs[4] (Bunch, |E|~1M, hidden 32, batch 1024) and Ebli at |E|~1M, each with live kernel timing.
+  weak_scaling  the same step at 512 trajectories per GPU (every N).
+  zero_skipping the same step with exact zero-skipping work lists (reported BESIDE the dense value, never as it).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,22 +48,116 @@ HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--edges", type=int, default=1_000_000, help="target |E| of the synthetic complex")
     ap.add_argument("--hidden", type=int, default=32)
-    ap.add_argument("--per-gpu-batch", type=int, default=512)
-    ap.add_argument("--cpu-sample", type=int, default=4, help="trajectories in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--spmm", type=int, default=1, help="also time the standalone dual SpMM (reported as extra)")
+    ap.add_argument("--global-batch", type=int, default=4096, help="trajectories per optimiser step over ALL ranks")
+    ap.add_argument("--per-gpu-batch", type=int, default=0,
+                    help="> 0: weak scaling instead -- this many trajectories per GPU (global batch = N x this)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="trajectories in the sparse CPU-baseline sample (0 = skip)")
+    ap.add_argument("--parity-sample", type=int, default=4, help="trajectories of the full-size oracle comparison (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="0: headline only (no other configs, no SpMM, no skipping modes)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")
     ap.add_argument("--skip-modes", default="zeros,field",
-                    help="also time the same step in these zero-skipping modes (reported beside the dense value; '' = none)")
+                    help="also time the 512-per-GPU step in these zero-skipping modes ('' = none)")
     return ap.parse_args()
 
 
-def cpu_baseline(cx, sc, flows, choice, last, hidden, n_sample):
-    """fwd + bwd of the reference formulation on the host: fp64 NumPy oracle with scipy CSR shifts."""
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh ranks (children) and wait.  Nothing here touches the GPU:
+    torch.cuda.device_count() does not initialise it on this image, and the children are new processes."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible\n" % (args.gpus, ndev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1): the oracle side, timed -- never part of `value`
+# ----------------------------------------------------------------------------------------------------------------
+
+def cpu_baseline_sparse(cx, sc, flows, choice, last, hidden, n_sample):
+    """B2: fp32 torch.sparse_csr restatement (multi-threaded), fwd + autograd bwd on n_sample trajectories of the workload."""
+    import warnings
+    import torch
+    from oracle import scone_oracle as so
+    from oracle import torch_sparse as ts
+    from scone_gcn_amd import synthetic_data_gen as g
+    warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
+    sel = np.arange(n_sample)
+    B1, B2 = g.incidence_matrices(cx)
+    L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+    Sl, Su = ts.csr_tensor(L_lo), ts.csr_tensor(L_up)
+    X = torch.from_numpy(flows.select(sel).todense())
+    y = torch.tensor(so.onehot_targets(choice[sel], sc.max_degree), dtype=torch.float32)
+    w = [torch.tensor(a, dtype=torch.float32) for a in so.generate_weights(1, [(3, hidden)] * 3, 1)]
+    rows = ts.make_inc_rows(B1, sc.nbrhoods)
+    t0 = time.perf_counter()
+    ts.loss_and_grad(w, Sl, Su, Sl, Su, rows, last[sel], X, y, 5e-5)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "dtype": "f32", "host_cpus": os.cpu_count(),
+            "sample": "%d trajectories of the same |E|=%d complex, hidden %d: reference formulation (TE:137-152, STM:42-56) "
+                      "in fp32 with torch.sparse_csr shifts (dense shifts do not exist at this size), forward + autograd "
+                      "backward, no optimiser, %d torch threads, %.1f s" % (n_sample, cx.n_edges, hidden,
+                                                                           torch.get_num_threads(), dt)}
+
+
+def cpu_baseline_dense_cfg1(steps=2):
+    """B1: the reference's own formulation on its own configuration (configs[0]: 400-point complex, 1000 trajectories,
+    hidden 16, batch 100): dense (E, E) fp32 shifts, forward over ALL N then mask (STM:46), autograd, Adam (STM:306-326)."""
+    import torch
+    from oracle import scone_oracle as so
+    from oracle import torch_dense as td
+    from scone_gcn_amd import synthetic_data_gen as g
+    cx = g.random_SC_graph(400)
+    paths = g.generate_random_walks(cx, m=1000, seed=1030)
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=7)
+    B1, B2 = (m.toarray() for m in g.incidence_matrices(cx))
+    L_lo, L_up = (torch.tensor(m, dtype=torch.float32) for m in so.scone_shifts(B1, B2))
+    nb, D = so.neighborhoods(cx.edges, cx.n_nodes)
+    B1x = torch.tensor(np.concatenate([B1, np.zeros((1, B1.shape[1]))]), dtype=torch.float32)
+    nbt = torch.as_tensor(nb)
+    X = torch.from_numpy(flows.todense())
+    y = torch.tensor(so.onehot_targets(choice, D), dtype=torch.float32)
+    ws = [torch.tensor(a, dtype=torch.float32, requires_grad=True) for a in so.generate_weights(1, [(3, 16)] * 3, 1)]
+    opt = torch.optim.Adam(ws, lr=1e-3, eps=1e-8)
+    rs = np.random.RandomState(1030)
+    train_mask = np.array([1] * 800 + [0] * 200)
+    lastt = torch.as_tensor(last)
+    times = []
+    for _ in range(steps + 1):
+        bm = torch.as_tensor(so.draw_batch_mask(rs, 1000, 100, train_mask))
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = td.scone_func(ws, L_lo, L_up, B1x, nbt, lastt, X)
+        td.loss_fn(out, y, bm, ws, 5e-5).backward()
+        opt.step()
+        times.append((time.perf_counter() - t0, int(bm.sum())))
+    dt = sum(t for t, _ in times[1:]) / steps
+    nb_mean = sum(n for _, n in times[1:]) / steps
+    return {"optimiser_steps_per_s": 1.0 / dt, "batch_trajectories_per_s": nb_mean / dt, "forward_trajectories_per_s": 1000 / dt,
+            "cores": int(torch.get_num_threads()), "dtype": "f32",
+            "sample": "configs[0]: |E|=%d, 1000 trajectories, hidden 16, batch 100 (~%d after the train mask): dense fp32 "
+                      "shifts, full-N forward then mask, autograd, Adam; %d steps after one warm-up, %.2f s/step"
+                      % (cx.n_edges, round(nb_mean), steps, dt)}
+
+
+def oracle_parity(cx, sc, net, inputs, flows, choice, last, hidden, n_sample):
+    """loss + every weight gradient of the HIP step vs the fp64 scipy-CSR oracle on n_sample full-size trajectories."""
     import scipy.sparse as sp
+    import torch
     from oracle import scone_oracle as so
     from scone_gcn_amd import synthetic_data_gen as g
     sel = np.arange(n_sample)
@@ -56,29 +167,120 @@ def cpu_baseline(cx, sc, flows, choice, last, hidden, n_sample):
     Bc = lambda n: B1x[sc.nbrhoods[n]].toarray()
     X = flows.select(sel).todense().astype(np.float64)
     y = so.onehot_targets(choice[sel], sc.max_degree)
-    w = so.generate_weights(1, [(3, hidden)] * 3, 1)
+    w = [t.detach().cpu().numpy().astype(np.float64) for t in net.weights]
     t0 = time.perf_counter()
-    so.scone_loss_and_grad(w, L_lo, L_up, Bc, last[sel], X, y, np.ones(n_sample, int), 5e-5)
+    ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, Bc, last[sel], X, y, np.ones(n_sample, int), 0.0)
     dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count()
-    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(threads), "kind": "port",
-            "sample": "%d trajectories of the same |E|=%d complex, hidden %d, fp64 NumPy + scipy CSR oracle, "
-                      "fwd+bwd (no optimiser), %.1f s" % (n_sample, cx.n_edges, hidden, dt)}
+    staged = net.stage(inputs, y, sel, skip="dense")
+    loss = float(net.grad_step_staged(inputs, staged, n_sample, apply=False))
+    got = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+    gmax = max(float(np.abs(r).max()) for r in ref_g)
+    err = max(float(np.abs(a - b).max()) for a, b in zip(got, ref_g))
+    return {"n": n_sample, "max_err": max(err, abs(loss - ref_loss)), "loss_err": abs(loss - ref_loss), "grad_max_abs_err": err,
+            "grad_err_rel_to_max_grad": err / gmax, "max_abs_grad": gmax, "tol": 1e-5, "oracle_s": dt,
+            "oracle": "oracle/scone_oracle.py, fp64 NumPy + scipy CSR, same trajectories / weights, |E|=%d, hidden %d" % (cx.n_edges, hidden)}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# one timed configuration
+# ----------------------------------------------------------------------------------------------------------------
+
+def time_config(net, inputs, staged, total, steps, warmup, sync, all_max):
+    """W untimed + K timed optimiser steps on resident micro-batches; returns (seconds over ranks (max), kernel table)."""
+    from scone_gcn_amd import ops
+    for _ in range(warmup):
+        net.grad_step_staged(inputs, staged, total)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.grad_step_staged(inputs, staged, total)
+    sync()
+    dt = all_max(time.perf_counter() - t0)
+    with ops.KernelTimer() as kt:                      # separate pass: the events do not sit in the timed region
+        net.grad_step_staged(inputs, staged, total)
+    return dt, kt.table()
+
+
+def dominant(table):
+    """(key, row) of the kernel family with the largest launches x mean time among those with a byte model."""
+    rows = {k: r for k, r in table.items() if r["alg_bytes"]}
+    if not rows:
+        return None, None
+    k = max(rows, key=lambda k: rows[k]["launches"] * rows[k]["avg_ms"])
+    return k, rows[k]
+
+
+def roofline_of(table, units_per_launch):
+    k, r = dominant(table)
+    if k is None:
+        return None
+    ach = r["alg_bytes"] / (r["avg_ms"] * 1e-3)
+    return {"bound": "hbm", "kernel": k, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+            "traffic": None, "launch_ms": r["avg_ms"], "launches_per_step": r["launches"],
+            "algorithmic_bytes_per_launch": r["alg_bytes"], "units_per_launch": units_per_launch}
+
+
+def slim(table):
+    return {k: {"launches": r["launches"], "avg_ms": round(r["avg_ms"], 4),
+                "GB/s": None if r["GB/s"] is None else round(r["GB/s"], 1)} for k, r in table.items()}
+
+
+def make_net(model, hidden, sc, flows, last, y, B, skip="dense"):
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    shifts, readout, _ = te.setup_from_complex(sc, model)
+    inputs = [readout, last, flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-3, B, 5e-5, verbose=False, skip_mode=skip)
+    net.setup(te.MODEL_FUNCS[model], [(7 if model == "bunch" else 3, hidden)] * 3, shifts, inputs, y, None, np.ones(B, int),
+              model_type=model)
+    return net, inputs
+
+
+def dataset(cx, sc, n, seed):
+    from scone_gcn_amd import synthetic_data_gen as g
+    paths = g.generate_random_walks(cx, m=n, seed=seed, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=seed + 7)
+    y = np.zeros((n, sc.max_degree, 1))
+    y[np.arange(n), choice, 0] = 1.0
+    return flows, choice, last, y
+
+
+def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data=None):
+    """One more BASELINE configuration on this GPU: step time, trajectories/s, its own dominant-kernel roofline."""
+    import torch
+    t0 = time.perf_counter()
+    flows, choice, last, y = data if data is not None else dataset(cx, sc, batch, seed)
+    net, inputs = make_net(model, hidden, sc, flows, last, y, batch)
+    staged = net.stage(inputs, y, np.arange(batch))
+    mb = staged[0][0].shape[0] * 4
+    torch.cuda.synchronize()
+    setup = time.perf_counter() - t0
+    dt, table = time_config(net, inputs, staged, batch, steps, 1, sync, lambda x: x)
+    out = {"workload": name, "model": model, "edges": cx.n_edges, "nodes": cx.n_nodes, "faces": cx.n_faces, "hidden": hidden,
+           "batch": batch, "micro_batch": mb, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value": batch * steps / dt, "unit": "trajectories/s", "plan": type(net._plan(inputs)).__name__,
+           "roofline": roofline_of(table, mb), "kernels": slim(table), "setup_s": round(setup, 1)}
+    alg = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
+    out["step_model"] = {"kernel_algorithmic_bytes_per_trajectory": alg / batch,
+                         "frac_of_hbm_peak_whole_step": out["value"] * alg / batch / HBM_PEAK}
+    del net, staged
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU\n" % (args.gpus, world))
+        sys.exit(2)
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
@@ -90,32 +292,8 @@ def main():
             dist.init_process_group("gloo")
 
     from scone_gcn_amd import ops
-    from scone_gcn_amd import scone_trajectory_model as stm
     from scone_gcn_amd import synthetic_data_gen as g
-    from scone_gcn_amd import trajectory_experiments as te
     from scone_gcn_amd.complex import SimplicialComplex
-
-    t_setup = time.perf_counter()
-    n_points = g.calibrate_n_points(args.edges)
-    cx = g.random_SC_graph(n_points)
-    sc = SimplicialComplex(cx)
-    B = args.per_gpu_batch
-    paths = g.generate_random_walks(cx, m=B, seed=1030 + rank, waypoint_pool=8, metric="euclid")
-    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=7 + rank)
-    D = sc.max_degree
-    y = np.zeros((B, D, 1))
-    y[np.arange(B), choice, 0] = 1.0
-    shifts, readout, _ = te.setup_from_complex(sc, "scone")
-    inputs = [readout, last, flows]
-    stm.reseed(1030)
-    net = stm.Scone_GCN(1, 1e-3, B, 5e-5, verbose=False)
-    net.setup(te.scone_func, [(3, args.hidden)] * 3, shifts, inputs, y, None, np.ones(B, int), model_type="scone")
-    staged = net.stage(inputs, y, np.arange(B))
-    total = B * world
-    plan = net._plan(inputs)
-    E, C = cx.n_edges, args.hidden
-    torch.cuda.synchronize()
-    t_setup = time.perf_counter() - t_setup
 
     def sync():
         torch.cuda.synchronize()
@@ -123,61 +301,115 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        net.grad_step_staged(inputs, staged, total)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net.grad_step_staged(inputs, staged, total)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def all_max(dt):
+        if world > 1:
+            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
 
-    # --- live per-kernel timing of the same step (separate pass so the events do not sit in the timed region)
-    with ops.KernelTimer() as kt:
-        net.grad_step_staged(inputs, staged, total)
-    ksum = kt.summary()
+    weak = args.per_gpu_batch > 0
+    if not weak and args.global_batch % world:
+        sys.stderr.write("bench.py: --global-batch must be a multiple of the rank count\n")
+        sys.exit(2)
+    B = args.per_gpu_batch if weak else args.global_batch // world         # this rank's trajectories per step
+    total = B * world
+
+    t_setup = time.perf_counter()
+    cx = g.random_SC_graph(g.calibrate_n_points(args.edges))
+    sc = SimplicialComplex(cx)
+    flows, choice, last, y = dataset(cx, sc, B, 1030 + rank)
+    net, inputs = make_net("scone", args.hidden, sc, flows, last, y, B)
+    staged = net.stage(inputs, y, np.arange(B))
+    plan = net._plan(inputs)
+    E, C = cx.n_edges, args.hidden
     mb = staged[0][0].shape[0] * ops.NS                     # trajectories per launch (micro-batch)
-    nnz_pat, nnz_lo, nnz_up = plan.nnz_pattern, plan.nnz_lower, plan.nnz_upper
-    csr_bytes = 4 * (nnz_lo + nnz_up) + 4 * nnz_pat + 4 * (E + 1)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
 
-    def alg_bytes(key):
-        # activation tensors read once + written once per launch, CSR once
-        if key.startswith("conv_fwd"):
-            cin = int(key.split("c")[2].split("->")[0])
-            cout = int(key.split("->")[1])
-            return 4.0 * E * mb * (cin + cout) + csr_bytes
-        if key.startswith("conv_bwd"):
-            cdz = int(key.split("c")[2].split("->")[0])
-            caux = int(key.split("->")[1].split()[0])
-            wr = 0 if "dW only" in key else caux
-            return 4.0 * E * mb * (cdz + caux + wr) + csr_bytes
-        if key.startswith("conv_dw_first"):                      # same tensors as the dW-only backward: dz and x, once
-            return 4.0 * E * mb * (int(key.split("c")[2]) + 1) + csr_bytes
-        return None
-    tot = {k: n * ms for k, (n, ms) in ksum.items()}
-    dom = max((k for k in tot if alg_bytes(k) is not None), key=lambda k: tot[k])
-    n_launch, ms = ksum[dom]
-    achieved = alg_bytes(dom) / (ms * 1e-3)
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/; same |E|, hidden and launch size only)
-    traffic = None
+    dt, table = time_config(net, inputs, staged, total, args.steps, args.warmup, sync, all_max)
+    value = total * args.steps / dt
+    roofline = roofline_of(table, mb)
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/; same |E|, hidden and launch size only;
+    # measured on dense random tensors with tools/pmc_traffic.sh)
     kmap = {"conv_bwd c32->32": "scn::bwd_c32_bf16_kernel", "conv_fwd c32->32": "scn::fwd_c32_w16_kernel",
-            "conv_fwd c1->32": "scn::fwd_c1_kernel", "conv_bwd c32->1 (dW only)": "scn::bwd_c1_kernel"}
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tfile) and dom in kmap and E == 996634 and mb == 128:
-        traffic = json.load(open(tfile)).get(kmap[dom], {}).get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic, "launch_ms": ms, "launches_per_step": n_launch,
-                "algorithmic_bytes_per_launch": alg_bytes(dom), "units_per_launch": mb,
-                "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE+WRITE_SIZE per launch)" if traffic else None}
-    kernels = {k: {"launches": n, "avg_ms": ms_, "GB/s": (alg_bytes(k) / (ms_ * 1e-3) / 1e9) if alg_bytes(k) else None}
-               for k, (n, ms_) in ksum.items()}
+            "conv_fwd c1->32": "scn::fwd_c1_kernel"}
+    for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if roofline and os.path.exists(tpath) and roofline["kernel"] in kmap and E == 996634 and mb == 128:
+            t = json.load(open(tpath)).get(kmap[roofline["kernel"]], {}).get("hbm_bytes_per_launch")
+            if t:
+                roofline["traffic"] = t
+                roofline["traffic_source"] = "profiles/%s (2*FETCH_SIZE+WRITE_SIZE per launch, dense random tensors)" % tfile
+                break
+    alg_step = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
+    survey_bytes = 4.0 * E * (15 * C + 2)
+    step_model = {"survey_model_bytes_per_trajectory": survey_bytes,
+                  "survey_model_frac_of_hbm_peak_whole_step": value / world * survey_bytes / HBM_PEAK,
+                  "kernel_algorithmic_bytes_per_trajectory": alg_step / B,
+                  "kernel_model_frac_of_hbm_peak_whole_step": value / world * (alg_step / B) / HBM_PEAK,
+                  "note": "survey model = SURVEY.md section 8d (4*E*(15*C+2): every activation tensor once per pass); kernel model "
+                          "= sum of the timed kernels' own algorithmic bytes (what `roofline` and `kernels` price)"}
 
-    extra = {}
-    if rank == 0:                                    # measured device-copy ceiling: 4 GiB read + 4 GiB write
+    line = {
+        "metric": "trajectories/sec fwd+bwd, 3-layer SCoNe |E|~1M batch=%d; SpMM HBM GB/s" % total, "value": value,
+        "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic complex |E|=%d (V=%d, F=%d), 3-layer SCoNe hidden=%d, global batch %d = %d "
+                               "trajectories/GPU x %d GPU(s), micro-batch %d, fwd+bwd+allreduce+Adam"
+                               % (E, cx.n_nodes, cx.n_faces, C, total, B, world, mb),
+                   "edges": E, "nodes": cx.n_nodes, "faces": cx.n_faces, "hidden": C, "global_batch": total,
+                   "per_gpu_batch": B, "micro_batch": mb, "parallelism": "dp%d" % world,
+                   "collective": ("%s all-reduce of %d fp32 weight gradients per step" % (args.backend, net._flat_g.numel()))
+                   if world > 1 else None,
+                   "nnz_lower": plan.nnz_lower, "nnz_upper": plan.nnz_upper, "nnz_pattern": plan.nnz_pattern},
+        "roofline": roofline, "cpu_baseline": None, "step_model": step_model, "kernels": slim(table), "setup_s": t_setup,
+    }
+
+    # ---- weak-scaling companion: 512 trajectories per GPU (every N), + the zero-skipping modes on the same batch
+    if args.extras and not weak:
+        nb = min(512, B)
+        sel = np.arange(nb)
+        st512 = net.stage(inputs, y, sel)
+        dtw, _ = time_config(net, inputs, st512, nb * world, max(2, min(args.steps, 5)), 1, sync, all_max)
+        ksteps = max(2, min(args.steps, 5))
+        line["weak_scaling"] = {"per_gpu_batch": nb, "global_batch": nb * world, "value": nb * world * ksteps / dtw,
+                                "unit": "trajectories/s", "ms_per_step": dtw / ksteps * 1e3, "steps": ksteps}
+        skipping = {}
+        for mode in [m for m in args.skip_modes.split(",") if m]:
+            st_m = net.stage(inputs, y, sel, skip=mode)
+            if st_m[0][3] is None:
+                continue
+            net.grad_step_staged(inputs, st_m, nb * world)                  # allocates the pooled zero buffers
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                net.grad_step_staged(inputs, st_m, nb * world)
+            sync()
+            dtm = all_max(time.perf_counter() - t1)
+            af = st_m[0][3]["active_fraction"]
+            skipping[mode] = {"value": nb * world * args.steps / dtm, "unit": "trajectories/s", "per_gpu_batch": nb,
+                              "ms_per_step": dtm / args.steps * 1e3,
+                              "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
+                              "note": "same step, same results; work items whose values are exactly zero"
+                                      + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
+            tf = os.path.join(ROOT, "profiles", "r01_skip_traffic.json")    # rocprofv3 --pmc passes of tools/pmc_skip.sh
+            if os.path.exists(tf) and E == 996634 and C == 32:
+                meas = json.load(open(tf))
+                skipping[mode]["hbm_bytes_per_trajectory"] = {
+                    "dense_model": survey_bytes, "measured_dense": meas["dense"]["hbm_bytes_per_trajectory"],
+                    "measured_this_mode": meas[mode]["hbm_bytes_per_trajectory"],
+                    "source": "profiles/r01_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
+            del st_m
+        if skipping:
+            line["zero_skipping"] = skipping
+        del st512
+    del staged
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and args.extras:
+        # measured device-copy ceiling: 4 GiB read + 4 GiB write
         src = torch.empty(1 << 30, device="cuda", dtype=torch.float32)
         dst = torch.empty_like(src)
         dst.copy_(src)
@@ -189,77 +421,71 @@ def main():
         torch.cuda.synchronize()
         roofline["measured_copy_GBps"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-    if args.spmm and rank == 0:
-        K = 128
+        # the SpMM metric and the two fused C=32 kernels on DENSE RANDOM tensors (no zeros to favour clocks or caches)
         S = 32
-        xr = torch.randn((S, E, K), device="cuda", dtype=torch.float32)      # dense random: no zero skipping
-        plan.conv.spmm_dual(xr)
+        xr = torch.randn((S, E, 4, C), device="cuda", dtype=torch.float32)
+        plan.conv.spmm_dual(xr.view(S, E, 4 * C))
         with ops.KernelTimer() as kt2:
             for _ in range(5):
-                plan.conv.spmm_dual(xr)
-        (nk, ms2), = kt2.summary().values()
-        b = 12.0 * E * K * S + csr_bytes
-        extra["spmm_dual"] = {"GB/s": b / (ms2 * 1e-3) / 1e9, "frac_of_8TBps": b / (ms2 * 1e-3) / HBM_PEAK,
-                              "ms": ms2, "x": "[%d, %d, %d] dense random fp32" % (S, E, K)}
+                plan.conv.spmm_dual(xr.view(S, E, 4 * C))
+        (_, r2), = kt2.table().items()
+        line["spmm_dual"] = {"GB/s": r2["GB/s"], "frac_of_8TBps": r2["GB/s"] * 1e9 / HBM_PEAK, "ms": r2["avg_ms"],
+                             "algorithmic_bytes": r2["alg_bytes"], "x": "[%d, %d, %d] dense random fp32" % (S, E, 4 * C)}
+        if C == 32:
+            Wr = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
+            aux = torch.tanh(torch.randn((S, E, 4, C), device="cuda"))
+            dWs = [torch.zeros_like(w) for w in Wr]
+            plan.conv.forward([xr], Wr, C, "tanh")
+            plan.conv.backward([xr], Wr, aux, "tanh", True, dWs)
+            with ops.KernelTimer() as kt3:
+                for _ in range(3):
+                    plan.conv.forward([xr], Wr, C, "tanh")
+                    plan.conv.backward([xr], Wr, aux, "tanh", True, dWs)
+            line["roofline"]["dense_random"] = {
+                k: {"ms": r["avg_ms"], "GB/s": r["GB/s"], "frac": r["GB/s"] * 1e9 / HBM_PEAK}
+                for k, r in kt3.table().items()}
+            del Wr, aux, dWs
         del xr
+        torch.cuda.empty_cache()
 
-    # --- the same step with exact zero-skipping (work lists): identical results, reported BESIDE the dense headline value
-    skipping = {}
-    for mode in [m for m in args.skip_modes.split(",") if m]:
-        st_m = net.stage(inputs, y, np.arange(B), skip=mode)
-        if st_m[0][3] is None:
-            continue
-        net.grad_step_staged(inputs, st_m, total)                           # warm-up (allocates the pooled zero buffers)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            net.grad_step_staged(inputs, st_m, total)
-        sync()
-        dtm = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dtm], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtm = float(t.item())
-        af = st_m[0][3]["active_fraction"]
-        skipping[mode] = {"value": total * args.steps / dtm, "unit": "trajectories/s", "ms_per_step": dtm / args.steps * 1e3,
-                          "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
-                          "note": "same step, same results; work items whose values are exactly zero"
-                                  + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
-        tf = os.path.join(ROOT, "profiles", "r01_skip_traffic.json")        # rocprofv3 --pmc passes of tools/pmc_skip.sh
-        if os.path.exists(tf) and E == 996634 and C == 32:
-            meas = json.load(open(tf))
-            skipping[mode]["hbm_bytes_per_trajectory"] = {
-                "dense_model": 4.0 * E * (15 * C + 2), "measured_dense": meas["dense"]["hbm_bytes_per_trajectory"],
-                "measured_this_mode": meas[mode]["hbm_bytes_per_trajectory"],
-                "source": "profiles/r01_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
-        del st_m
+        if args.parity_sample > 0:
+            line["parity"] = oracle_parity(cx, sc, net, inputs, flows, choice, last, C, args.parity_sample)
+        if args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline_sparse(cx, sc, flows, choice, last, C, args.cpu_sample)
+            line["cpu_baseline"]["dense_faithful_configs0"] = cpu_baseline_dense_cfg1()
+        del net
+        torch.cuda.empty_cache()
 
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        cpu = cpu_baseline(cx, sc, flows, choice, last, args.hidden, args.cpu_sample)
+        configs = {}
+        # configs[4]: Bunch (SCCONV), same complex, hidden 32, batch 1024; Ebli (SNN) beside it
+        configs["configs[4] bunch"] = side_config("BASELINE configs[4]: -model bunch, |E|~1M, hidden 32, batch 1024", "bunch",
+                                                  cx, sc, 32, 1024, 2, sync)
+        configs["ebli"] = side_config("-model ebli (SNN), |E|~1M, hidden 32, batch 128", "ebli", cx, sc, 32, 128, 3, sync)
+        del plan, inputs
+        # configs[1]: |E| ~ 50k, hidden 16, batch 1024
+        cx2 = g.random_SC_graph(g.calibrate_n_points(50_000))
+        sc2 = SimplicialComplex(cx2)
+        configs["configs[1]"] = side_config("BASELINE configs[1]: synthetic |E|~50k, hidden 16, batch 1024", "scone", cx2, sc2,
+                                            16, 1024, 10, sync)
+        # configs[2]: ocean drifters, full training batch (the trajectories of tests/golden/buoy.npz)
+        bpath = os.path.join(ROOT, "tests", "golden", "buoy.npz")
+        if os.path.exists(bpath):
+            from scone_gcn_amd import buoy_data as bd
+            gld = np.load(bpath)
+            trajs = [gld["traj_nodes"][gld["traj_ptr"][i]:gld["traj_ptr"][i + 1]].astype(int).tolist()
+                     for i in range(len(gld["traj_ptr"]) - 1)]
+            cx3, _, fl3, ch3, last3, _, train_mask, _ = bd.buoy_dataset(gld["elist"].astype(np.int64), gld["tlist"].astype(np.int64),
+                                                                       gld["coords"], trajs)
+            sc3 = SimplicialComplex(cx3)
+            tr = np.nonzero(train_mask)[0]
+            y3 = np.zeros((len(tr), sc3.max_degree, 1))
+            y3[np.arange(len(tr)), ch3[tr], 0] = 1.0
+            configs["configs[2]"] = side_config("BASELINE configs[2]: ocean drifters, 3-layer SCoNe hidden 16, full training batch",
+                                                "scone", cx3, sc3, 16, len(tr), 20, sync,
+                                                data=(fl3.select(tr), ch3[tr], last3[tr], y3))
+        line["configs"] = configs
 
     if rank == 0:
-        value = total * args.steps / dt
-        bytes_per_traj = 4.0 * E * (15 * C + 2)
-        line = {
-            "metric": "trajectories/sec fwd+bwd, 3-layer SCoNe |E|~1M batch=4096", "value": value,
-            "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic complex |E|=%d (V=%d, F=%d), 3-layer SCoNe hidden=%d, %d trajectories/GPU "
-                                   "(global batch %d), fwd+bwd+allreduce+Adam" % (E, cx.n_nodes, cx.n_faces, C, B, total),
-                       "edges": E, "nodes": cx.n_nodes, "faces": cx.n_faces, "hidden": C, "global_batch": total,
-                       "micro_batch": mb, "parallelism": "dp%d" % world,
-                       "nnz_lower": nnz_lo, "nnz_upper": nnz_up, "nnz_pattern": nnz_pat},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "step_model": {"algorithmic_bytes_per_trajectory": bytes_per_traj,
-                           "frac_of_hbm_peak_whole_step": value / world * bytes_per_traj / HBM_PEAK},
-            "kernels": kernels, "setup_s": t_setup,
-        }
-        line.update(extra)
-        if skipping:
-            line["zero_skipping"] = skipping
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

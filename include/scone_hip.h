@@ -179,7 +179,8 @@ int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
                               int32_t act, float* dz, void* stream);
 
 /* Scatter ragged edge flows into a zeroed slab tensor [n_slabs][n_edges][ns][1] (the flows_in input,
- * SDG:327-344): x[slab(n)][perm? idx][n % ns] = val.  sample_of[i] gives the trajectory of entry i. */
+ * SDG:327-344): x[slab(n)][idx][n % ns] += val (repeated (trajectory, edge) entries accumulate, like the reference's
+ * f[k] += 1).  sample_of[i] gives the trajectory of entry i. */
 int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_entries,
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
@@ -248,6 +249,12 @@ int scn_conv_dw_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float*
  * identity != 0: the operator also reads the row itself. */
 int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t identity, int32_t* order,
                           uint8_t* block_start);
+
+/* Masked cross-entropy of one micro-batch (the data term of STM:54 and its gradient w.r.t. the log-probabilities):
+ *   d_logp[i] = y[i] * scale   (scale = -1 / number of trajectories in the GLOBAL batch; padding rows have y = 0)
+ *   loss[0]  += sum_i logp[i] * d_logp[i]    (fp64 accumulator on the device, fixed summation order)
+ * n = trajectories x max_deg entries of logp / y / d_logp. */
+int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, void* stream);
 
 /* Fused Adam + ridge step on the flat parameter buffer (jax.experimental.optimizers.adam as driven by
  * STM:300-326; ridge term of STM:54-56):   g' = g * g_scale + 2*weight_decay*w ; m,v EMA ;

@@ -318,6 +318,32 @@ def accuracy_from_preds(preds, y, mask, n_nbrs):
     return float(np.mean(np.argmax(p[m], axis=1) == np.argmax(y[m], axis=1)))     # STM:63, 70-71
 
 
+def two_target_accuracy_from_preds(preds, y, mask, n_nbrs, rs, random_targets=None):
+    """STM:73-108 on given log-probabilities; rs = the global NumPy stream (onp.random), random_targets = the cached draw
+    (self.random_targets) or None.  Returns (accuracy, random_targets).  Quirks kept: the redraw compares against the
+    PREDICTED choice, and pred_choice (masked, a jax array) is indexed by the unmasked i -- jax clamps an out-of-range
+    index to the last element.  (A node with a single neighbour whose prediction is slot 0 would loop forever in the
+    reference; such rows keep their draw here.)"""
+    N = len(preds)
+    n_nbrs = np.asarray(n_nbrs)
+    if random_targets is None:
+        random_targets = rs.randint(0, high=n_nbrs, size=N)                       # STM:79
+    p = np.array(preds, dtype=np.float64)
+    for i in range(N):
+        p[i, n_nbrs[i]:] = -100                                                   # STM:84-85
+    m = np.asarray(mask) == 1
+    pred_choice = np.argmax(p[m], axis=1).reshape(-1)                             # STM:87
+    for i in range(N):                                                            # STM:89-91
+        pc = pred_choice[min(i, len(pred_choice) - 1)]
+        while n_nbrs[i] > 1 and random_targets[i] == pc:
+            random_targets[i] = rs.randint(0, high=n_nbrs[i])
+    rows = np.arange(N)
+    random_probs = p[rows, random_targets, 0]                                     # STM:94-95
+    true_probs = p[rows, np.argmax(y, axis=1).reshape(N), 0]                      # STM:97-98
+    t, r = true_probs[m], random_probs[m]
+    return float((np.sum(t > r) + 0.5 * np.sum(t == r)) / np.sum(m)), random_targets   # STM:101-108
+
+
 # ----------------------------------------------------------------------------------------------
 # hand-derived backward of loss(weights) for scone / ebli  (what grad(self.loss) computes, STM:307)
 # ----------------------------------------------------------------------------------------------

@@ -88,6 +88,7 @@ SIGNATURES = {
                                               ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_clear_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_plan_refine_order": (ctypes.c_int, [c_i32, P_i32, P_i32, c_i32, P_i32, c_void_p]),
+    "scn_masked_ce": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_f32, c_void_p, c_void_p, c_void_p]),
     "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_void_p]),
 }

@@ -199,6 +199,168 @@ class Bconds:
         return np.cumsum(ptr).astype(np.int32), edge.astype(np.int32), sign.astype(np.float32), edge_nodes
 
 
+# ----------------------------------------------------------------------------------------------
+# adoption of reference-style arguments: a caller that built its operands the way the reference's
+# data_setup does -- dense (E, E) ndarrays for the shifts (TE:240-257), a closure for Bconds_func (TE:298-303) -- hands
+# them to scone_func / ebli_func / bunch_func unchanged; they are wrapped ONCE (cached on the object) in the native
+# types.  Meant for the small complexes where dense operands exist at all; no locality reordering is attempted.
+# ----------------------------------------------------------------------------------------------
+_IDENTITY_LAYOUTS = {}
+_ADOPTED = {}            # id(object) -> (object kept alive, wrapper)
+
+
+def identity_layout(sizes):
+    sizes = tuple(int(x) for x in sizes)
+    if sizes not in _IDENTITY_LAYOUTS:
+        _IDENTITY_LAYOUTS[sizes] = Layout(sizes)
+    return _IDENTITY_LAYOUTS[sizes]
+
+
+def _to_csr(S):
+    if sp.issparse(S):
+        return S.tocsr().astype(np.float64)
+    if hasattr(S, "detach"):                                  # torch tensor
+        S = S.detach().cpu().numpy()
+    a = np.asarray(S, dtype=np.float64)
+    if a.ndim != 2:
+        raise TypeError("a shift operator must be a 2-D matrix (dense, scipy.sparse) or a Shift")
+    return sp.csr_matrix(a)
+
+
+def adopt_shift(S, layout, row_level, col_level):
+    """Shift for a dense / scipy / torch matrix in the caller's index order (cached on the object's identity)."""
+    if isinstance(S, Shift):
+        return S
+    hit = _ADOPTED.get(id(S))
+    if hit is not None and hit[0] is S and hit[1].layout is layout:
+        return hit[1]
+    sh = Shift(_to_csr(S), layout, row_level, col_level)
+    _ADOPTED[id(S)] = (S, sh)
+    return sh
+
+
+class ProbedBconds:
+    """Readout operand for a plain callable Bcond_func(n) -> (D, E) array of B1 rows (TE:298-303): the rows are read off
+    by CALLING it for the last nodes that actually occur, and the sparse tables the HIP readout needs are rebuilt from
+    what came back.  A row is taken to be the incidence row of one node (entries +-1 up to a per-edge flip, every edge in
+    at most two rows with opposite signs); an all-zero row is a padding slot (the appended zero row, TE:288)."""
+
+    def __init__(self, fn, n_edges, layout):
+        self.fn, self.n_edges, self.layout = fn, int(n_edges), layout
+        self.version = 0
+        self._slot = {}            # last node -> row of the table
+        self._node = {}            # bytes of an incidence row -> pseudo node id
+        self._rows = []            # pseudo node id -> (edge idx, sign)
+        self._table = []           # per probed last node: list of pseudo ids (-1 = zero row)
+        self.nbrhoods = np.zeros((0, 1), np.int64)
+        self.flips = None
+
+    def __call__(self, n):
+        return self.fn(n)
+
+    def prepare(self, last_nodes):
+        """Probe the nodes not seen yet; returns last_nodes remapped to rows of this object's tables."""
+        ln = np.asarray(last_nodes.cpu() if hasattr(last_nodes, "cpu") else last_nodes).astype(np.int64).ravel()
+        grew = False
+        for u in np.unique(ln):
+            if int(u) in self._slot:
+                continue
+            M = self.fn(int(u))
+            M = np.asarray(M.detach().cpu().numpy() if hasattr(M, "detach") else M, dtype=np.float64)
+            if M.ndim != 2 or M.shape[1] != self.n_edges:
+                raise TypeError("Bcond_func(n) must return a (D, E) array of incidence rows (TE:298-303)")
+            ids = []
+            for row in M:
+                e = np.flatnonzero(row)
+                if len(e) == 0:
+                    ids.append(-1)
+                    continue
+                key = (e.tobytes(), row[e].tobytes())
+                if key not in self._node:
+                    self._node[key] = len(self._rows)
+                    self._rows.append((e.astype(np.int64), row[e].copy()))
+                ids.append(self._node[key])
+            self._slot[int(u)] = len(self._table)
+            self._table.append(ids)
+            grew = True
+        if grew:
+            D = max(len(t) for t in self._table)
+            if any(len(t) != D for t in self._table):
+                raise TypeError("Bcond_func must return the same number of rows for every node")
+            self.nbrhoods = np.asarray(self._table, np.int64).reshape(len(self._table), D)
+            self.version += 1
+        return np.asarray([self._slot[int(u)] for u in ln], np.int64)
+
+    def incidence_tables(self):
+        """Same layout as Bconds.incidence_tables, over the pseudo nodes discovered so far (unseen endpoints: -2)."""
+        pe = self.layout.perm[1]
+        node = np.concatenate([np.full(len(e), k, np.int64) for k, (e, _) in enumerate(self._rows)] or [np.zeros(0, np.int64)])
+        edge = np.concatenate([pe[e] for e, _ in self._rows] or [np.zeros(0, np.int64)])
+        sign = np.concatenate([v for _, v in self._rows] or [np.zeros(0)])
+        order = np.lexsort((edge, node))
+        node, edge, sign = node[order], edge[order], sign[order]
+        ptr = np.zeros(len(self._rows) + 1, np.int64)
+        np.add.at(ptr, node + 1, 1)
+        edge_nodes = np.full((self.n_edges, 2), -2, np.int32)
+        fill = np.zeros(self.n_edges, np.int64)
+        first_sign = np.zeros(self.n_edges)
+        for k, e, v in zip(node, edge, sign):
+            if fill[e] == 2 or (fill[e] == 1 and v * first_sign[e] > 0):
+                raise TypeError("Bcond_func does not select incidence rows: an edge must appear in at most two rows, with "
+                                "opposite signs")
+            if fill[e] == 0:
+                first_sign[e] = v
+            edge_nodes[e, fill[e]] = k
+            fill[e] += 1
+        return np.cumsum(ptr).astype(np.int32), edge.astype(np.int32), sign.astype(np.float32), edge_nodes
+
+
+def adopt_bconds(fn, n_edges, layout):
+    if isinstance(fn, Bconds) or isinstance(fn, ProbedBconds):
+        return fn
+    if not callable(fn):
+        raise TypeError("Bcond_func must be callable: the Bconds object of SimplicialComplex.bconds() or a function n -> (D, E) rows")
+    hit = _ADOPTED.get(id(fn))
+    if hit is not None and hit[0] is fn and hit[1].layout is layout:
+        return hit[1]
+    pb = ProbedBconds(fn, n_edges, layout)
+    _ADOPTED[id(fn)] = (fn, pb)
+    return pb
+
+
+class _Degrees:
+    def __init__(self, deg):
+        self._deg = deg
+
+    def __getitem__(self, n):
+        return int(self._deg[n])
+
+    def __iter__(self):
+        return iter((i, int(d)) for i, d in enumerate(self._deg))
+
+    def __len__(self):
+        return len(self._deg)
+
+
+class UndirGraph:
+    """What the reference's data_setup hands back as G_undir (a networkx graph read from G_undir.pkl, SDG:436 -- gpickle
+    no longer exists), reduced to the accesses the experiment driver makes (TE:273-279, 456-458, 500): .nodes, .edges,
+    .degree (iterable of (node, degree) and indexable), G[node] -> neighbours; .complex is the SimplicialComplex."""
+
+    def __init__(self, sc):
+        self.complex = sc
+        self.nodes = range(sc.cx.n_nodes)
+        self.edges = [tuple(e) for e in sc.cx.edges.tolist()]
+        self.degree = _Degrees(sc.degrees)
+
+    def __getitem__(self, n):
+        row = self.complex.nbrhoods[int(n)]
+        return [int(v) for v in row[row >= 0]]
+
+    def neighbors(self, n):
+        return iter(self[n])
+
+
 class SimplicialComplex:
     """Complex + layout + operator factory.  Build from arrays, from a Complex, or from B1/B2 (dense or sparse)."""
 

@@ -187,7 +187,30 @@ __global__ void scatter_flows_kernel(int ns, int n_edges, int64_t n_entries, con
     if (t >= n_entries) return;
     const int n = sample_of[t];
     const int s = n / ns, i = n - s * ns;
-    x[((size_t)s * n_edges + edge_idx[t]) * ns + i] = val[t];
+    // accumulate: the reference builds a flow with f[k] += +-1 per traversed edge (SDG:327-344), so a repeated
+    // (trajectory, edge) entry adds up -- like SparseFlows.todense() on the host (x is zeroed just before)
+    atomicAdd(&x[((size_t)s * n_edges + edge_idx[t]) * ns + i], val[t]);
+}
+
+// masked cross-entropy of STM:54 for one micro-batch: d_logp = y * scale (scale = -1 / global batch size) and
+// loss[0] += sum logp * d_logp in fp64, one block, fixed summation order
+__global__ __launch_bounds__(1024) void masked_ce_kernel(int64_t n, const float* __restrict__ logp,
+                                                         const float* __restrict__ y, float scale,
+                                                         float* __restrict__ d_logp, double* __restrict__ loss) {
+    __shared__ double part[1024];
+    double acc = 0.0;
+    for (int64_t t = threadIdx.x; t < n; t += 1024) {
+        const float d = y[t] * scale;
+        d_logp[t] = d;
+        acc += (double)logp[t] * (double)d;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] += part[0];
 }
 
 __global__ void adam_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
@@ -298,6 +321,14 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
                            n_edges, n_entries, sample_of, edge_idx, val, x);
         SCN_LAUNCH_CHECK();
     }
+    return SCN_OK;
+}
+
+int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, void* stream) {
+    if (n <= 0) return SCN_ERR_BAD_SHAPE;
+    if (!logp || !y || !d_logp || !loss) return SCN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, logp, y, scale, d_logp, loss);
+    SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
 

@@ -68,8 +68,11 @@ def generate_dataset(n, m, folder, holes=True, seed=1030):
     nbr, deg = sdg.neighborhood_table(cx)
     D = nbr.shape[1]
 
+    kept = []
+
     def both_hops(ps):
         prefixes, suffixes, last1 = sdg.split_paths(ps, rs, True, 2)
+        kept.append(prefixes)
         f1 = sdg.paths_to_flows(cx, prefixes)
         t1 = np.asarray([s[0] for s in suffixes])
         c1 = np.argmax(nbr[np.asarray(last1)] == t1[:, None], axis=1)
@@ -89,7 +92,25 @@ def generate_dataset(n, m, folder, holes=True, seed=1030):
         np.save(os.path.join(fol, 'last_nodes.npy'), fw[h][2]); np.save(os.path.join(fol, 'target_nodes.npy'), fw[h][3])
         _save_flows(fol, 'rev_flows_in', rv[h][0]); np.save(os.path.join(fol, 'rev_targets.npy'), rv[h][1])
         np.save(os.path.join(fol, 'rev_last_nodes.npy'), rv[h][2]); np.save(os.path.join(fol, 'rev_target_nodes.npy'), rv[h][3])
+        if h == 0:                                            # the optional prefixes file (TE:282), ragged instead of pickled
+            np.savez(os.path.join(fol, 'prefixes.npz'), ptr=np.concatenate([[0], np.cumsum([len(p) for p in kept[0]])]),
+                     nodes=np.concatenate([np.asarray(p, np.int64) for p in kept[0]]))
     return cx
+
+
+def load_prefixes(folder):
+    """prefixes of the 1-hop folder as a list of node lists, or None when the folder has none (TE:281-284)."""
+    p = os.path.join(folder, 'prefixes.npz')
+    if os.path.exists(p):
+        d = np.load(p)
+        return [d['nodes'][d['ptr'][i]:d['ptr'][i + 1]].astype(int).tolist() for i in range(len(d['ptr']) - 1)]
+    p = os.path.join(folder, 'prefixes.npy')
+    if os.path.exists(p):
+        try:
+            return [list(map(int, q)) for q in np.load(p, allow_pickle=False)]
+        except ValueError:
+            return None                                       # a pickled object array: not read (no pickle at this boundary)
+    return None
 
 
 def load_dataset(folder):

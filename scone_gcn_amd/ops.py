@@ -18,40 +18,58 @@ NS = 4   # trajectories per slab
 
 class KernelTimer:
     """Optional per-call timing with events on the launch stream (torch's current stream), used by bench.py to get
-    the average duration of one kernel family live.  Disabled (None) by default: no events, no overhead."""
-    active = None
+    the average duration of one kernel family live, together with the ALGORITHMIC bytes of every timed call (each operand
+    tensor read once, each result written once, the operator's CSR arrays once -- SURVEY.md section 8d).  Disabled by
+    default: no events, no overhead.  Timers nest (a stack): every active timer sees the calls made while it is open."""
+    _stack = []
 
     def __init__(self):
         self.records = {}
 
     def __enter__(self):
-        KernelTimer.active = self
+        KernelTimer._stack.append(self)
         return self
 
     def __exit__(self, *a):
-        KernelTimer.active = None
+        KernelTimer._stack.remove(self)
 
     def summary(self):
+        """key -> (launches, mean ms)."""
         torch.cuda.synchronize()
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.records.items()}
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v) / max(len(v), 1)) for k, v in self.records.items()}
+
+    def table(self):
+        """key -> {"launches", "avg_ms", "alg_bytes" (mean per launch, None where no model is stated), "GB/s"}."""
+        torch.cuda.synchronize()
+        out = {}
+        for k, v in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in v) / max(len(v), 1)
+            nb = [n for _, _, n in v if n is not None]
+            alg = sum(nb) / len(nb) if nb else None
+            out[k] = {"launches": len(v), "avg_ms": ms, "alg_bytes": alg,
+                      "GB/s": (alg / (ms * 1e-3) / 1e9) if (alg and ms > 0) else None}
+        return out
 
 
 class _timed:
-    def __init__(self, key):
-        self.key = key
+    def __init__(self, key, nbytes=None):
+        self.key, self.nbytes = key, nbytes
 
     def __enter__(self):
-        t = KernelTimer.active
-        if t is not None:
+        if KernelTimer._stack:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *a):
-        t = KernelTimer.active
-        if t is not None:
+        if KernelTimer._stack:
             self.b.record()
-            t.records.setdefault(self.key, []).append((self.a, self.b))
+            for t in KernelTimer._stack:
+                t.records.setdefault(self.key, []).append((self.a, self.b, self.nbytes))
+
+
+def _nbytes(*tensors):
+    return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
 def _stream():
@@ -126,6 +144,8 @@ class ConvOp:
         self.n_slots = len(self.slot_group)
         self.nnz = [int(descs[g].nnz) for g in range(len(groups))]
         self.n_vals = [int(descs[g].n_vals) for g in range(len(groups))]
+        # column indices + every value array + row pointers, once per launch
+        self.csr_bytes = float(sum(4 * self.nnz[g] * (1 + self.n_vals[g]) + 4 * (self.n_rows + 1) for g in range(len(groups))))
         del keep
 
     def __del__(self):
@@ -155,7 +175,7 @@ class ConvOp:
             assert tuple(w.shape) == (c_in[self.slot_group[s]], c_out), "weight shape"
         if out is None:
             out = torch.empty((S, self.n_rows, ns, c_out), device=srcs[0].device, dtype=torch.float32)
-        with _timed("conv_fwd c%s->%d" % ("+".join(map(str, c_in)), c_out)):
+        with _timed("conv_fwd c%s->%d" % ("+".join(map(str, c_in)), c_out), None if wl is not None else _nbytes(out, *srcs) + self.csr_bytes):
             check(lib.scn_conv_forward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
                                             ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out),
                                             wl.ref() if wl is not None else None, _stream()), "scn_conv_forward")
@@ -179,7 +199,8 @@ class ConvOp:
         ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
         if need_dx and dx is None:
             dx = torch.empty_like(aux)
-        with _timed("conv_bwd c%s->%d%s" % ("+".join(map(str, c_dz)), c_aux, "" if need_dx else " (dW only)")):
+        with _timed("conv_bwd c%s->%d%s" % ("+".join(map(str, c_dz)), c_aux, "" if need_dx else " (dW only)"),
+                    None if wl is not None else _nbytes(aux, dx if need_dx else None, *dzs) + self.csr_bytes):
             check(lib.scn_conv_backward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
                                              ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
                                              _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
@@ -199,7 +220,7 @@ class ConvOp:
             out = torch.empty((S, self.n_rows, ns, c_out), device=x.device, dtype=torch.float32)
         if y is None:
             y = torch.empty((S, self.n_rows, ns, 3), device=x.device, dtype=torch.float32)
-        with _timed("conv_fwd c1->%d" % c_out):
+        with _timed("conv_fwd c1->%d" % c_out, None if wl is not None else _nbytes(x, out) + self.csr_bytes):
             st = lib.scn_conv_forward_first(self.handle, S, ns, _dev(x), ptr_array([_dev(w).value for w in Ws]), c_out,
                                             ACT[act], _dev(out), _dev(y), wl.ref() if wl is not None else None, _stream())
         if st == _lib.SCN_ERR_UNSUPPORTED:
@@ -213,7 +234,7 @@ class ConvOp:
         lib = _lib.load()
         S, rows, ns, c = x.shape
         out = torch.empty_like(x)
-        with _timed("conv_fwd_power c%d" % c):
+        with _timed("conv_fwd_power c%d" % c, _nbytes(x0, x, out) + self.csr_bytes):
             st = lib.scn_conv_forward_power(self.handle, S, ns, _dev(x0), _dev(x), ptr_array([_dev(w).value for w in Ws]), c,
                                             ACT[act], _dev(out), _stream())
         if st == _lib.SCN_ERR_UNSUPPORTED:
@@ -230,7 +251,7 @@ class ConvOp:
             return False, None
         ws = torch.empty(nbytes, device=dz.device, dtype=torch.uint8)
         dx = torch.empty_like(aux) if need_dx else None
-        with _timed("conv_bwd_power c%d" % c):
+        with _timed("conv_bwd_power c%d" % c, _nbytes(dz, g1, aux, dx) + self.csr_bytes):
             check(lib.scn_conv_backward_power(self.handle, S, ns, _dev(dz), _dev(g1), ptr_array([_dev(w).value for w in Ws]),
                                               _dev(aux), c, ACT[act], _dev(dx) if need_dx else None,
                                               ptr_array([_dev(d).value for d in dWs]), ctypes.c_void_p(ws.data_ptr()),
@@ -258,7 +279,7 @@ class ConvOp:
         if nbytes == 0:
             return False
         ws = torch.empty(nbytes, device=dz.device, dtype=torch.uint8)
-        with _timed("conv_dw_first c%d" % c):
+        with _timed("conv_dw_first c%d" % c, None if wl is not None else _nbytes(dz) + 4.0 * S * rows * ns + self.csr_bytes):
             check(lib.scn_conv_dw_first(self.handle, S, ns, _dev(x) if x is not None else None,
                                         _dev(y) if y is not None else None, _dev(dz), c,
                                         ptr_array([_dev(d).value for d in dWs]), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
@@ -271,7 +292,7 @@ class ConvOp:
         assert rows == self.group_cols[0]
         ya = torch.empty((S, self.n_rows, k), device=x.device, dtype=torch.float32)
         yb = torch.empty_like(ya) if dual else None
-        with _timed("spmm_dual k%d" % k if dual else "spmm k%d" % k):
+        with _timed("spmm_dual k%d" % k if dual else "spmm k%d" % k, _nbytes(x, ya, yb) + self.csr_bytes):
             check(lib.scn_spmm_dual(self.handle, S, k, _dev(x), _dev(ya), _dev(yb) if dual else None, _stream()),
                   "scn_spmm_dual")
         return ya, yb
@@ -291,7 +312,7 @@ def dense_terms_forward(Gs, Ws, c_out, act):
         out = dense_terms_forward([g.view(S, R, ns // 2, 32) for g in Gs], [torch.block_diag(w, w) for w in Ws], 32, act)
         return out.view(S, R, ns, 16)
     out = torch.empty((S, R, ns, c_out), device=Gs[0].device, dtype=torch.float32)
-    with _timed("dense_fwd x%d ->%d" % (len(Gs), c_out)):
+    with _timed("dense_fwd x%d ->%d" % (len(Gs), c_out), _nbytes(out, *Gs)):
         check(lib.scn_dense_terms_forward(S * R * ns, len(Gs), ptr_array([_dev(g).value for g in Gs]),
                                           i32_array([g.shape[3] for g in Gs]), ptr_array([_dev(w).value for w in Ws]),
                                           c_out, ACT[act], _dev(out), _stream()), "scn_dense_terms_forward")
@@ -313,7 +334,7 @@ def dense_terms_backward(Gs, Ws, aux, act, need_dx, dWs):
     nbytes = lib.scn_dense_terms_backward_workspace(n_points, len(Gs), cs, c_aux)
     ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
     dx = torch.empty_like(aux) if need_dx else None
-    with _timed("dense_bwd x%d" % len(Gs)):
+    with _timed("dense_bwd x%d" % len(Gs), _nbytes(aux, dx, *Gs)):
         check(lib.scn_dense_terms_backward(n_points, len(Gs), ptr_array([_dev(g).value for g in Gs]), cs,
                                            ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
                                            _dev(dx) if need_dx else None, ptr_array([_dev(d).value for d in dWs]),
@@ -374,6 +395,17 @@ def batch_to_slabs(t, layout, level, ns=NS):
     return t.index_select(1, order).reshape(Np // ns, ns, R, C).permute(0, 2, 1, 3).contiguous()
 
 
+def remap_last_nodes(plan, last_nodes):
+    """Last nodes as the plan's readout tables index them: the caller's node ids for a Bconds object; for a probed
+    Bcond_func closure (complex.ProbedBconds) the rows of its table, probing nodes it has not seen yet."""
+    bc = getattr(plan, "bconds", None)
+    if bc is not None and hasattr(bc, "prepare"):
+        ln = bc.prepare(last_nodes)
+        plan.sync_readout()
+        return ln
+    return last_nodes
+
+
 def _last_nodes_dev(last_nodes, n_pad, device):
     ln = np.zeros(n_pad, np.int32)
     a = last_nodes.detach().cpu().numpy() if torch.is_tensor(last_nodes) else np.asarray(last_nodes)
@@ -397,15 +429,32 @@ class SconePlan:
         E = S_lower.shape[0]
         self.n_edges = E
         self._init_operators(S_lower, S_upper)
+        self.bconds = bconds
+        self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
+        self._zero_pool = {}                            # zero-skipping mode: all-zero activation / gradient buffers
+        self._blocks = None                             # (block of row, block adjacency), built on first use
+        self._upload_readout()
+
+    def _upload_readout(self):
+        """Device copies of the readout tables (TE:279, 288, 298-303).  A ProbedBconds (plain Bcond_func closure) grows as
+        new last nodes are probed: sync_readout() re-uploads when its version has moved."""
+        bconds, device = self.bconds, self.device
         ptr, edge, sign, edge_nodes = bconds.incidence_tables()
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.inc_ptr, self.inc_edge, self.inc_sign, self.edge_nodes = to(ptr), to(edge), to(sign), to(edge_nodes)
-        self.nbr = to(bconds.nbrhoods.astype(np.int32))
-        self.n_nodes, self.max_deg = bconds.nbrhoods.shape
-        self._dz_zero = {}                              # all-zero readout-gradient buffers, by shape (see backward)
-        self._h_nbr, self._h_inc_ptr, self._h_inc_edge = np.asarray(bconds.nbrhoods), np.asarray(ptr), np.asarray(edge)
-        self._zero_pool = {}                            # zero-skipping mode: all-zero activation / gradient buffers
-        self._blocks = None                             # (block of row, block adjacency), built on first use
+        nbr = np.asarray(bconds.nbrhoods)
+        if nbr.shape[0] == 0:
+            nbr = -np.ones((1, 1), np.int64)
+        self.nbr = to(nbr.astype(np.int32))
+        self.n_nodes, self.max_deg = nbr.shape
+        self._h_nbr, self._h_inc_ptr, self._h_inc_edge = nbr, np.asarray(ptr), np.asarray(edge)
+        self._ro_rows = None
+        self._readout_version = getattr(bconds, "version", 0)
+        self._probed = hasattr(bconds, "prepare")
+
+    def sync_readout(self):
+        if getattr(self.bconds, "version", 0) != self._readout_version:
+            self._upload_readout()
 
     def _init_operators(self, S_lower, S_upper):
         E = self.n_edges
@@ -474,16 +523,21 @@ class SconePlan:
     def _trajectory_supports(self, flow, last_nodes, n_layers):
         """Per TRAJECTORY and layer l = 1..L, as 0/1 matrices (N x n_blocks): Z[l] blocks holding a row where H_l can be
         non-zero, D[l] blocks holding a row the loss can see (support of the gradient of layer l's pre-activation), F[l]
-        blocks holding a row that is both.  Computed once per dataset (cached on the identity of the inputs): supports are
+        blocks holding a row that is both.  Computed once per dataset (cached on a hash of the inputs' content): supports are
         tracked per ROW -- one hop = the operator's own pattern -- and only then mapped to plan blocks."""
         import scipy.sparse as sp
+        import hashlib
         ln = np.asarray(last_nodes)
-        if isinstance(flow, SparseFlows):                    # identity + a content fingerprint (in-place edits must miss)
-            fp = (len(flow), int(flow.ptr[-1]), int(flow.idx.sum()), float(np.abs(flow.val).sum()))
+        h = hashlib.blake2b(digest_size=16)                  # keyed on CONTENT: an in-place edit of the inputs must miss
+        if isinstance(flow, SparseFlows):
+            for a in (flow.ptr, flow.idx, flow.val):
+                h.update(np.ascontiguousarray(a).view(np.uint8))
         else:
-            fa = np.asarray(flow)
-            fp = (fa.shape, float(np.abs(fa.reshape(-1)[::max(1, fa.size // 65536)]).sum()))
-        key = (id(flow), id(last_nodes), n_layers, fp, int(ln.sum()), int(ln[:64].dot(np.arange(len(ln[:64])))))
+            fa = flow.detach().cpu().numpy() if torch.is_tensor(flow) else np.asarray(flow)
+            h.update(str(fa.shape).encode())
+            h.update(np.ascontiguousarray(fa).view(np.uint8))
+        h.update(np.ascontiguousarray(ln, np.int64).view(np.uint8))
+        key = (n_layers, h.hexdigest())
         c = getattr(self, "_act_cache", None)
         if c is not None and c["key"] == key:
             return c
@@ -509,7 +563,7 @@ class SconePlan:
         need[n_layers] = ones(sel @ self._readout_rows())
         for l in range(n_layers - 1, 0, -1):
             need[l] = hop(need[l + 1])
-        c = {"key": key, "keep": (flow, last_nodes), "N": N, "nb": nb,
+        c = {"key": key, "N": N, "nb": nb,
              "Z": [None] + [blocks(rows[l]) for l in range(1, n_layers + 1)],
              "D": [None] + [blocks(need[l]) for l in range(1, n_layers + 1)],
              "F": [None] + [blocks(rows[l].multiply(need[l])) for l in range(1, n_layers + 1)]}
@@ -523,7 +577,7 @@ class SconePlan:
         on the edges around the last nodes; each layer below needs one more hop).  None when the shape is not served by the
         work-list kernels."""
         import scipy.sparse as sp
-        if mode in (None, "dense") or hidden not in (16, 32) or not self.conv.plan_info()[0]:
+        if mode in (None, "dense") or hidden not in (16, 32) or not self.conv.plan_info()[0] or self._probed:
             return None
         c = self._trajectory_supports(flow, last_nodes, n_layers)
         sel = np.arange(c["N"]) if sel is None else np.asarray(sel)

@@ -12,13 +12,15 @@ selects (the reference runs all N and masks afterwards, STM:46 -- same value), t
 fp32 buffer so that the gradient all-reduce and the fused Adam/ridge kernel see a single array, and the batch
 sharded over ranks when torch.distributed is initialised (scone_gcn_amd/distributed.py).
 """
+import ctypes
+
 import numpy as np
 import torch
 
 from . import _lib, ops
 from . import distributed as dp
 from .synthetic_data_gen import SparseFlows
-from .trajectory_experiments import MODEL_ACT, MODEL_FUNCS
+from .trajectory_experiments import MODEL_ACT, MODEL_FUNCS, resolve_operands
 
 # module-level legacy RNG seeded like the reference's `onp.random.seed(1030)` at import (STM:15): weights
 # (STM:237), batch-mask shuffles (STM:320) and random targets (STM:79, 91) are drawn from it in call order.
@@ -128,9 +130,10 @@ class Scone_GCN():
     def _plan(self, inputs):
         if self.model is MODEL_FUNCS.get(self.model_type):
             dev = ops.default_device()
+            shifts, readout = resolve_operands(self.model_type, self.shifts, inputs[0])   # dense / closure operands: wrapped once
             if self.model_type == 'bunch':
-                return ops.get_bunch_plan(list(self.shifts), inputs[0], dev)
-            return ops.get_scone_plan(self.shifts[0], self.shifts[1], inputs[0], MODEL_ACT[self.model_type], dev)
+                return ops.get_bunch_plan(shifts, readout, dev)
+            return ops.get_scone_plan(shifts[0], shifts[1], readout, MODEL_ACT[self.model_type], dev)
         return None
 
     # ------------------------------------------------------------------ loss / metrics
@@ -182,9 +185,11 @@ class Scone_GCN():
         for i in range(len(preds)):
             preds[i, n_nbrs[i]:] = -100
         m = np.asarray(mask) == 1
-        pred_choice = np.argmax(preds[m], axis=1)
-        for i in range(min(preds.shape[0], len(pred_choice))):
-            while n_nbrs[i] > 1 and self.random_targets[i] == pred_choice[i]:
+        pred_choice = np.argmax(preds[m], axis=1).reshape(-1)
+        for i in range(N):
+            # pred_choice is a jax array in the reference: an index past its end is clamped to the last element (STM:90)
+            pc = pred_choice[min(i, len(pred_choice) - 1)]
+            while n_nbrs[i] > 1 and self.random_targets[i] == pc:     # (n_nbrs == 1 would never terminate: keep the draw)
                 self.random_targets[i] = _RNG.randint(0, high=n_nbrs[i])
         rows = np.arange(N)
         random_probs = preds[rows, self.random_targets, 0]
@@ -210,7 +215,7 @@ class Scone_GCN():
             sel = idx[c0:c0 + mb]
             sub = _select(inputs, sel)
             x, n = ops.flows_to_slabs(sub[2], plan.layout, device)
-            last_dev = ops._last_nodes_dev(sub[1], x.shape[0] * ops.NS, device)
+            last_dev = ops._last_nodes_dev(ops.remap_last_nodes(plan, sub[1]), x.shape[0] * ops.NS, device)
             D = np.asarray(y).shape[1]
             yt = torch.zeros((x.shape[0] * ops.NS, D), device=device, dtype=torch.float32)
             yt[:n] = torch.as_tensor(np.asarray(y)[sel], dtype=torch.float32).reshape(n, -1).to(device)
@@ -223,14 +228,16 @@ class Scone_GCN():
     def _accumulate_staged(self, plan, staged, total):
         """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches.  Returns that partial loss
         as a 0-dim device tensor (no host synchronisation inside the step)."""
-        part = torch.zeros((), device=self._flat_w.device, dtype=torch.float64)
+        lib = _lib.load()
+        part = torch.zeros((1,), device=self._flat_w.device, dtype=torch.float64)
         for x, last_dev, yt, activity in staged:
             logp, saved = plan.forward(x, last_dev, self.weights, activity) if activity else plan.forward(x, last_dev, self.weights)
-            d_logp = yt * (-1.0 / total)
-            part += (logp.double() * d_logp.double()).sum()
+            d_logp = torch.empty_like(logp)
+            _lib.check(lib.scn_masked_ce(logp.numel(), ops._dev(logp), ops._dev(yt), -1.0 / total, ops._dev(d_logp),
+                                         ctypes.c_void_p(part.data_ptr()), ops._stream()), "scn_masked_ce")
             plan.backward(saved, logp, d_logp, last_dev, self.weights, self._grads)
             del saved
-        return part
+        return part[0]
 
     def _accumulate_grad(self, plan, inputs, y, idx, total):
         return self._accumulate_staged(plan, self.stage(inputs, y, idx), total)
@@ -302,9 +309,10 @@ class Scone_GCN():
             batch_mask = np.array(unshuffled_batch_mask)
             _RNG.shuffle(batch_mask)
             batch_mask = np.logical_and(batch_mask, train_mask)
-            if batch_mask.sum() == 0:
-                continue
-            self.grad_step(inputs, y, batch_mask)
+            if batch_mask.sum() > 0:
+                self._step = i                                    # update_fun(i, ...): bias correction with the LOOP index (STM:310)
+                self.grad_step(inputs, y, batch_mask)
+            # (an empty batch has no gradient: the reference would divide by zero there; only the step is skipped)
             if i % n_batches == n_batches - 1:                    # STM:328-337
                 train_loss = self.loss(self.weights, inputs, y, train_mask)
                 train_acc = self.accuracy(self.shifts, inputs, y, train_mask, n_nbrs)

@@ -248,6 +248,23 @@ def paths_to_flows(cx, paths):
     return SparseFlows(np.asarray(ptr, np.int64), idx.astype(np.int64), val.astype(np.float32), cx.n_edges)
 
 
+def flow_to_path(flow, edges, last_node):
+    """Node path of a +-1 edge flow that ends in last_node (SDG:299-325): walk backwards along the oriented edges."""
+    flow = np.asarray(flow).reshape(-1)
+    into = {}
+    for i in np.flatnonzero(flow):
+        a, b = (int(edges[i][0]), int(edges[i][1])) if flow[i] > 0 else (int(edges[i][1]), int(edges[i][0]))
+        into.setdefault(b, []).append(a)                       # oriented edge a -> b
+    path, cur, left = [int(last_node)], int(last_node), int(np.count_nonzero(flow))
+    while left:
+        if not into.get(cur):
+            raise ValueError("flow is not a path ending in last_node")
+        cur = into[cur].pop()
+        path.append(cur)
+        left -= 1
+    return path[::-1]
+
+
 def neighborhood_table(cx):
     """nbrhoods (V, D): sorted neighbours, -1 padded (TE:273-279); also degrees."""
     G = adjacency(cx)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .complex import Bconds, SimplicialComplex
+from .complex import Bconds, Shift, SimplicialComplex, adopt_bconds, adopt_shift, identity_layout
 from .synthetic_data_gen import SparseFlows
 
 MODEL_ACT = {"scone": "tanh", "ebli": "leaky_relu", "bunch": "relu"}
@@ -83,13 +83,34 @@ def _run_batched(fn_cls, plan, weights, last_nodes, flow, widths, rows_total):
     return logp[:N].unsqueeze(-1)
 
 
+def resolve_operands(model_type, shifts, readout):
+    """Native operands for what a caller passed: Shift / Bconds objects go through untouched; dense ndarrays, torch tensors
+    or scipy matrices (the reference's L1_lower, L1_upper, S_ab -- TE:240-257) and a plain Bcond_func closure (TE:298-303)
+    are wrapped once and cached on the object (small complexes; identity row order)."""
+    shifts = list(shifts)
+    if all(isinstance(m, Shift) for m in shifts):
+        layout = shifts[0].layout
+    elif model_type == 'bunch':
+        sizes = (shifts[0].shape[0], shifts[3].shape[0], shifts[6].shape[0])          # S_00 (V,V), S_11 (E,E), S_22 (F,F)
+        layout = next((m.layout for m in shifts if isinstance(m, Shift)), None) or identity_layout(sizes)
+        lv = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2)]
+        shifts = [adopt_shift(m, layout, r, c) for m, (r, c) in zip(shifts, lv)]
+    else:
+        E = shifts[0].shape[0]
+        layout = next((m.layout for m in shifts if isinstance(m, Shift)), None) or identity_layout((1, E, 1))
+        shifts = [adopt_shift(m, layout, 1, 1) for m in shifts]
+    if model_type == 'bunch':
+        return shifts, np.asarray(readout.cpu() if torch.is_tensor(readout) else readout)
+    return shifts, adopt_bconds(readout, shifts[0].shape[0], layout)
+
+
 def _scone_like(weights, S_lower, S_upper, Bcond_func, last_node, flow, act):
     n_layers = (len(weights) - 1) / 3
     assert n_layers % 1 == 0, 'wrong number of weights'                    # TE:141-142 / 159-160
-    if not isinstance(Bcond_func, Bconds):
-        raise TypeError("Bcond_func must be the Bconds object returned by data_setup / SimplicialComplex.bconds()")
-    plan = ops.get_scone_plan(S_lower, S_upper, Bcond_func, act, ops.default_device())
+    (S_lower, S_upper), bconds = resolve_operands('scone', [S_lower, S_upper], Bcond_func)
+    plan = ops.get_scone_plan(S_lower, S_upper, bconds, act, ops.default_device())
     ln, f, single = _prep_batch(last_node, flow)
+    ln = ops.remap_last_nodes(plan, ln)
     widths = [1] + [int(weights[3 * i].shape[1]) for i in range(int(n_layers))]
     out = _run_batched(ops._SconeFn, plan, weights, ln, f, widths, plan.n_edges)
     return out[0] if single else out
@@ -109,7 +130,7 @@ def bunch_func(weights, S_00, S_10, S_01, S_11, S_21, S_12, S_22, nbrhoods, last
     """Forward pass of the Bunch (SCCONV) model (TE:173-203); relu on all three levels."""
     n_layers = (len(weights)) / 7
     assert n_layers % 1 == 0, 'wrong number of weights'                    # TE:177-178
-    shifts = [S_00, S_10, S_01, S_11, S_21, S_12, S_22]
+    shifts, nbrhoods = resolve_operands('bunch', [S_00, S_10, S_01, S_11, S_21, S_12, S_22], nbrhoods)
     plan = ops.get_bunch_plan(shifts, nbrhoods, ops.default_device())
     ln, f, single = _prep_batch(last_node, flow)
     widths = [1] + [int(weights[7 * i].shape[1]) for i in range(int(n_layers))]
@@ -124,9 +145,11 @@ MODEL_FUNCS = {"scone": scone_func, "ebli": ebli_func, "bunch": bunch_func}
 # data setup (TE:206-311) on an in-memory or on-disk dataset
 # ----------------------------------------------------------------------------------------------
 
-def setup_from_complex(sc, model='scone', flip_edges=False):
-    """shifts + readout operand for a SimplicialComplex (TE:214-219, 240-260, 270-309)."""
-    flips = sc.flip_vector(1) if flip_edges else None
+def setup_from_complex(sc, model='scone', flip_edges=False, flips=None):
+    """shifts + readout operand for a SimplicialComplex (TE:214-219, 240-260, 270-309).  flips: an explicit +-1 vector
+    (data_setup draws it from the trainer's global stream like the reference); flip_edges=True draws it under seed 1."""
+    if flips is None:
+        flips = sc.flip_vector(1) if flip_edges else None
     if model == 'scone':
         shifts = sc.scone_shifts(flips)
     elif model == 'ebli':
@@ -149,9 +172,17 @@ def apply_flips(flows, flips):
 
 
 def data_setup(hops=(1,), load=True, folder_suffix='schaub', hp=None):
-    """Imports and sets up flow, target, and shift matrices for model training (TE:206-311)."""
-    from .dataset_io import load_dataset, generate_dataset
+    """Imports and sets up flow, target, and shift matrices for model training (TE:206-311).  Returns the reference's
+    eleven values (TE:311): inputs_all, y_all, train_mask, test_mask, shifts, G_undir, E_lookup, nbrhoods, n_nbrs,
+    target_nodes_all, prefixes -- shifts as sparse Shift objects and Bconds_func as a Bconds object (both also answer the
+    dense questions the reference asks of them: .shape, @, .toarray(), Bconds_func(n))."""
+    from .complex import UndirGraph
+    from .dataset_io import load_dataset, generate_dataset, load_prefixes
+    from .synthetic_data_gen import flow_to_path
     hp = HYPERPARAMS if hp is None else hp
+    if hp['flip_edges']:                                                   # TE:214-219: the GLOBAL stream is reseeded with 1 and
+        from . import scone_trajectory_model as stm                        # the flips are drawn from it, so the weights drawn
+        stm.reseed(1)                                                      # afterwards (STM:237) continue that stream
     if not load:
         generate_dataset(400, 1000, folder=folder_suffix, holes=bool(hp['holes']))
         raise Exception('Data generation done')                            # TE:225
@@ -165,21 +196,34 @@ def data_setup(hops=(1,), load=True, folder_suffix='schaub', hp=None):
         target_nodes_all.append(target_nodes)
         inputs_all.append([None, np.array(last_nodes), X])
         y_all.append(y)
-    shifts, readout, flips = setup_from_complex(sc, hp['model'], bool(hp['flip_edges']))
+    flips = None
+    if hp['flip_edges']:
+        from . import scone_trajectory_model as stm
+        flips = stm._RNG.choice([1, -1], size=sc.cx.n_edges, replace=True, p=[0.8, 0.2]).astype(np.float64)
+    shifts, readout, flips = setup_from_complex(sc, hp['model'], flips=flips)
     for i in range(len(inputs_all)):
         inputs_all[i][-1] = apply_flips(inputs_all[i][-1], flips)
         inputs_all[i][0] = readout
     last_nodes = inputs_all[0][1]
     n_nbrs = sc.n_nbrs(last_nodes)
-    E_lookup = {tuple(e): i for i, e in enumerate(map(tuple, sc.cx.edges.tolist()))}   # TE:263-268
-    return inputs_all, y_all, train_mask, test_mask, shifts, sc, E_lookup, sc.nbrhoods, n_nbrs, target_nodes_all
+    edges = [tuple(e) for e in sc.cx.edges.tolist()]
+    E_lookup = {e: i for i, e in enumerate(edges)}                          # TE:263-268
+    prefixes = load_prefixes('trajectory_data_1hop_' + folder_suffix)      # TE:281-284
+    if prefixes is None:
+        X0 = inputs_all[0][-1]
+        dense = X0.todense() if isinstance(X0, SparseFlows) else np.asarray(X0)
+        if flips is not None:
+            dense = dense * flips.reshape(1, -1, 1)                         # undo X F: paths live on the unflipped orientation
+        prefixes = [flow_to_path(dense[i], edges, last_nodes[i]) for i in range(len(last_nodes))]
+    return inputs_all, y_all, train_mask, test_mask, shifts, UndirGraph(sc), E_lookup, sc.nbrhoods, n_nbrs, \
+        target_nodes_all, prefixes
 
 
 def train_model(hp=None):
     """Trains a model to predict the next node in each input path (TE:313-510, Markov block excluded)."""
     from .scone_trajectory_model import Scone_GCN
     hp = hyperparams() if hp is None else hp
-    inputs_all, y_all, train_mask, test_mask, shifts, sc, E_lookup, nbrhoods, n_nbrs, target_nodes_all = \
+    inputs_all, y_all, train_mask, test_mask, shifts, G_undir, E_lookup, nbrhoods, n_nbrs, target_nodes_all, prefixes = \
         data_setup(hops=(1, 2), load=hp['load_data'], folder_suffix=hp['data_folder_suffix'], hp=hp)
     (inputs_1hop, inputs_2hop), (y_1hop, y_2hop) = inputs_all, y_all
     in_axes = tuple(([None] * len(shifts)) + [None, None, 0, 0])          # TE:325
@@ -194,8 +238,9 @@ def train_model(hp=None):
         train_mask = np.array([1 if i % 3 == 1 else 0 for i in range(len(y_1hop))])
         test_mask = np.array([1 if i % 3 == 2 else 0 for i in range(len(y_1hop))])
     if hp['describe'] == 1:                                                # TE:456-461
-        print('Graph nodes: {}, edges: {}, avg degree: {}'.format(sc.cx.n_nodes, sc.cx.n_edges,
-                                                                  np.average(sc.degrees)))
+        print('Graph nodes: {}, edges: {}, avg degree: {}'.format(len(G_undir.nodes), len(G_undir.edges),
+                                                                  np.average([G_undir.degree[node] for node in
+                                                                              G_undir.nodes])))
         print('Training paths: {}, Test paths: {}'.format(train_mask.sum(), test_mask.sum()))
         print('Model: {}'.format(hp['model']))
     os.makedirs('models', exist_ok=True)
@@ -215,14 +260,15 @@ def train_model(hp=None):
         scone.two_target_accuracy(shifts, inputs_1hop, y_1hop, test_mask, n_nbrs)
     scone.test(inputs_1hop, y_1hop, test_mask, n_nbrs)
     print('2-target accs:', train_2target, test_2target)
+    results = {"train_2target": train_2target, "test_2target": test_2target}
     if hp['reverse']:                                                      # TE:497-504
         from .dataset_io import load_reverse
         rev_flows_in, rev_targets_1hop, rev_last_nodes = load_reverse('trajectory_data_1hop_' + hp['data_folder_suffix'])
-        flips = sc.flip_vector(1) if hp['flip_edges'] else None
-        rev_n_nbrs = sc.n_nbrs(rev_last_nodes)
+        rev_n_nbrs = np.asarray([len(G_undir[n]) for n in rev_last_nodes])                # TE:501
         print('Reverse experiment:')
-        scone.test([inputs_1hop[0], rev_last_nodes, apply_flips(rev_flows_in, flips)], rev_targets_1hop, test_mask,
-                   rev_n_nbrs)
+        # (as in the reference, the reversed flows are fed as stored -- NOT multiplied by F under -flip_edges, TE:499-504)
+        results["reverse"] = scone.test([inputs_1hop[0], rev_last_nodes, rev_flows_in], rev_targets_1hop, test_mask, rev_n_nbrs)
+    scone.experiment_results = results
     return scone, (train_loss, train_acc, test_loss, test_acc)
 
 

@@ -35,3 +35,17 @@ def cfg1():
         "rev_flows": so.flows_from_ragged(p["rev_flow1_ptr"], p["rev_flow1_idx"], p["rev_flow1_val"], E),
         "rev_targets": so.onehot_targets(p["rev_targets1"], D), "rev_last_nodes": p["rev_last1"].astype(np.int64),
     }
+
+
+@pytest.fixture(scope="session")
+def big_complex():
+    """The benchmark complex (|E| = 996 634, BASELINE configs[3] / [4]) and its SimplicialComplex: built once per session,
+    GPU tests only (the layout pass calls into the library, the tests that use it need the device anyway)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(g.calibrate_n_points(1_000_000))
+    assert abs(cx.n_edges - 1_000_000) < 20_000
+    return cx, SimplicialComplex(cx)

@@ -1,0 +1,377 @@
+"""GPU tests of the boundary and the host harness (through the C-ABI): reference-style operands (dense ndarray shifts, a plain
+Bcond_func closure -- TE:240-257, 298-303), the experiment driver train_model() with its -reverse / -regional / -flip_edges
+branches (TE:313-510) against an oracle trainer on the same RNG stream, the two-rank data-parallel gradient step through the HIP
+path, the bf16x3 exact-split kernels against their fp32-MFMA predecessors on wide-dynamic-range data, and flow inputs with
+repeated entries."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import scone_oracle as so
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _maxdiff(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b))))
+
+
+def _rand_weights(shapes, scale, seed):
+    rs = np.random.RandomState(seed)
+    return [scale * rs.randn(*s) for s in shapes]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reference-style operands
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("model", ["scone", "ebli", "bunch"])
+def test_dense_shifts_and_a_plain_bcond_closure_run_unchanged(cfg1, model):
+    """A caller that built its operands like the reference's data_setup (dense L1_lower / L1_upper / S_ab ndarrays, the
+    Bconds_func closure over B1_jax and nbrhoods) calls the model functions and the trainer with them: same log-probabilities
+    and gradients as the oracle."""
+    _need_gpu()
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    B1, B2 = cfg1["B1"], cfg1["B2"]
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    sel = np.arange(9)
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    mask = np.ones(len(sel), int)
+    if model == "bunch":
+        shifts = so.bunch_shifts(B1, B2)                                   # seven dense ndarrays (TE:255-257)
+        readout = nb                                                       # nbrhoods (TE:309)
+        w = _rand_weights(so.weight_shapes(1, [(7, 8)] * 3, 1, "bunch"), 0.4, 3)
+        ref = so.bunch_forward(w, shifts, nb, last, X)
+        ref_loss, ref_g = so.bunch_loss_and_grad(w, shifts, nb, last, X, y, mask, 0.0)
+        fn = te.bunch_func
+    else:
+        shifts = so.scone_shifts(B1, B2) if model == "scone" else so.ebli_shifts(B1, B2)   # dense (E, E) ndarrays (TE:240-253)
+        B1_jax = np.append(B1, np.zeros((1, B1.shape[1])), axis=0)         # TE:288
+
+        def readout(n):                                                    # TE:298-303, verbatim semantics
+            return B1_jax[nb[n]]
+        w = _rand_weights(so.weight_shapes(1, [(3, 16)] * 3, 1), 0.3 if model == "scone" else 0.1, 4)
+        act = "tanh" if model == "scone" else "leaky_relu"
+        ref = so.scone_forward(w, shifts[0], shifts[1], readout, last, X, act=act)
+        ref_loss, ref_g = so.scone_loss_and_grad(w, shifts[0], shifts[1], readout, last, X, y, mask, 0.0, act=act)
+        fn = te.MODEL_FUNCS[model]
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = fn(wt, *shifts, readout, last, X)
+    assert _maxdiff(out.detach().cpu().numpy(), ref) <= TOL
+    loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / len(sel)
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL
+    for a, b in zip(wt, ref_g):
+        assert _maxdiff(a.grad.cpu().numpy(), b) <= TOL
+    # second call: other last nodes (the closure is probed for the new ones), per-sample call, and the trainer surface
+    sel2 = np.arange(20, 27)
+    ref2 = (so.bunch_forward(w, shifts, nb, cfg1["last_nodes"][sel2], cfg1["flows"][sel2]) if model == "bunch" else
+            so.scone_forward(w, shifts[0], shifts[1], readout, cfg1["last_nodes"][sel2], cfg1["flows"][sel2], act=act))
+    out2 = fn(w, *shifts, readout, cfg1["last_nodes"][sel2], cfg1["flows"][sel2])
+    assert _maxdiff(out2.cpu().numpy(), ref2) <= TOL
+    one = fn(w, *shifts, readout, int(cfg1["last_nodes"][21]), cfg1["flows"][21])
+    assert one.shape == (D, 1) and _maxdiff(one.cpu().numpy(), ref2[1]) <= TOL
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-3, len(sel), 0.0, verbose=False)
+    k = 7 if model == "bunch" else 3
+    hl = [(k, 8)] * 3 if model == "bunch" else [(3, 16)] * 3
+    net.setup(fn, hl, shifts, [readout, last, X], y, None, mask, model_type=model)
+    for a, b in zip(net.weights, w):
+        a.copy_(torch.as_tensor(b, dtype=torch.float32))
+    net.grad_step([readout, last, X], y, mask, apply=False)
+    for a, b in zip(net._grads, ref_g):
+        assert _maxdiff(a.cpu().numpy(), b) <= TOL
+    assert abs(net.loss(net.weights, [readout, last, X], y, mask) - ref_loss) <= TOL
+
+
+def test_repeated_flow_entries_accumulate(cfg1):
+    """A SparseFlows with the same (trajectory, edge) twice means f[k] += v twice (SDG:327-344): device scatter == host todense."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.synthetic_data_gen import Complex, SparseFlows
+    cx = Complex(n_nodes=cfg1["n_nodes"], edges=cfg1["edges"].astype(np.int64), faces=cfg1["faces"].astype(np.int64),
+                 coords=cfg1["coords"])
+    sc = SimplicialComplex(cx)
+    fl = SparseFlows(np.array([0, 4, 6], np.int64), np.array([3, 9, 3, 3, 7, 7], np.int64),
+                     np.array([1, -1, 1, 1, 2, -2], np.float32), cfg1["E"])
+    x, n = ops.flows_to_slabs(fl, sc.layout, ops.default_device())
+    back = ops.slabs_to_batch(x, sc.layout, 1, n).cpu().numpy()
+    assert np.array_equal(back, fl.todense())
+    assert back[0, 3, 0] == 3.0 and back[1, 7, 0] == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# experiment driver
+# ------------------------------------------------------------------------------------------------------------------
+
+def _oracle_driver(hp, folder_suffix):
+    """The reference driver's sequence (TE:313-510, STM:215-368) on the oracle: same global RNG stream for flips, weights,
+    batch masks and random targets."""
+    from scone_gcn_amd import dataset_io
+    model = hp["model"]
+    f1 = "trajectory_data_1hop_" + folder_suffix
+    X, (B1s, B2s), y, train_mask, test_mask, coords, last, tnodes = dataset_io.load_dataset(f1)
+    B1, B2 = B1s.toarray(), B2s.toarray()
+    X = np.asarray(X, np.float64)
+    N = len(last)
+    rs = np.random.RandomState(1030)
+    F = None
+    if hp["flip_edges"]:
+        rs = np.random.RandomState(1)
+        F = np.diag(rs.choice([1, -1], size=B1.shape[1], replace=True, p=[0.8, 0.2]).astype(np.float64))
+        X = X * np.diag(F)[None, :, None]
+    edges = np.array([(np.nonzero(B1[:, e] < 0)[0][0], np.nonzero(B1[:, e] > 0)[0][0]) for e in range(B1.shape[1])])
+    nb, D = so.neighborhoods(edges, B1.shape[0])
+    n_nbrs = (nb[last] >= 0).sum(1)
+    if model == "bunch":
+        shifts = so.bunch_shifts(B1, B2)
+        k, wshape = 7, so.weight_shapes(1, hp["hidden_layers"], 1, "bunch")
+        fwd = lambda w, ln, XX: so.bunch_forward(w, shifts, nb, ln, XX)
+        lg = lambda w, m: so.bunch_loss_and_grad(w, shifts, nb, last, X, y, m, hp["weight_decay"])
+    else:
+        shifts = so.scone_shifts(B1, B2, F) if model == "scone" else so.ebli_shifts(B1, B2, F)
+        act = "tanh" if model == "scone" else "leaky_relu"
+        Bc = so.make_Bconds(B1, nb, F)
+        k, wshape = 3, so.weight_shapes(1, hp["hidden_layers"], 1)
+        fwd = lambda w, ln, XX: so.scone_forward(w, shifts[0], shifts[1], Bc, ln, XX, act=act)
+        lg = lambda w, m: so.scone_loss_and_grad(w, shifts[0], shifts[1], Bc, last, X, y, m, hp["weight_decay"], act=act)
+    w = [(0.01 * rs.randn(*s)).astype(np.float32).astype(np.float64) for s in wshape]
+    if hp["regional"]:
+        train_mask = np.array([1 if i % 3 == 1 else 0 for i in range(N)])
+        test_mask = np.array([1 if i % 3 == 2 else 0 for i in range(N)])
+    adam = so.Adam(w, hp["learning_rate"])
+    bs = int(hp["batch_size"])
+    n_batches = int(train_mask.sum()) // bs
+    for i in range(int(hp["epochs"]) * n_batches):
+        bm = so.draw_batch_mask(rs, N, bs, train_mask)
+        if bm.sum() == 0:
+            continue
+        adam.update(i, lg(adam.x, bm)[1])
+    out = fwd(adam.x, last, X)
+    res = (so.loss_from_preds(out, y, train_mask, adam.x, hp["weight_decay"]), so.accuracy_from_preds(out, y, train_mask, n_nbrs),
+           so.loss_from_preds(out, y, test_mask, adam.x, hp["weight_decay"]), so.accuracy_from_preds(out, y, test_mask, n_nbrs))
+    t2_train, rt = so.two_target_accuracy_from_preds(out, y, train_mask, n_nbrs, rs)
+    t2_test, rt = so.two_target_accuracy_from_preds(out, y, test_mask, n_nbrs, rs, random_targets=rt)
+    extra = {"train_2target": t2_train, "test_2target": t2_test}
+    if hp["reverse"]:
+        rX, ry, rl = dataset_io.load_reverse(f1)
+        rout = fwd(adam.x, rl, np.asarray(rX, np.float64))                  # stored reverse flows, not flipped (TE:499-504)
+        rn = (nb[rl] >= 0).sum(1)
+        extra["reverse"] = (so.loss_from_preds(rout, ry, test_mask, adam.x, hp["weight_decay"]),
+                            so.accuracy_from_preds(rout, ry, test_mask, rn))
+    return adam.x, res, extra
+
+
+@pytest.mark.parametrize("flags", [["-model", "scone"], ["-model", "ebli"], ["-model", "bunch", "-hidden_layers", "7_8_7_8_7_8"],
+                                   ["-model", "scone", "-reverse", "1"], ["-model", "scone", "-regional", "1"],
+                                   ["-model", "scone", "-flip_edges", "1", "-reverse", "1"]])
+def test_train_model_driver_matches_the_oracle_driver(tmp_path, monkeypatch, flags):
+    """train_model() (TE:313-510) end to end on a generated 150-point dataset: final weights, the returned losses / accuracies,
+    both 2-target accuracies (STM:73-108, same random-target stream) and the reverse experiment, for every model and for the
+    -reverse / -regional / -flip_edges branches (TE:449-453, 497-504, 214-219)."""
+    _need_gpu()
+    from scone_gcn_amd import dataset_io, scone_trajectory_model as stm, trajectory_experiments as te
+    monkeypatch.chdir(tmp_path)
+    dataset_io.generate_dataset(150, 45, folder="drv", holes=True)
+    hp = te.hyperparams(["prog", "-epochs", "2", "-batch_size", "12", "-data_folder_suffix", "drv", "-describe", "1",
+                         "-learning_rate", "0.01"] + flags)
+    if "-hidden_layers" not in flags:
+        hp["hidden_layers"] = [(3, 16)] * 3
+    stm.reseed(1030)
+    net, res = te.train_model(hp)
+    ref_w, ref_res, ref_extra = _oracle_driver(hp, "drv")
+    for a, b in zip(net.weights, ref_w):
+        assert _maxdiff(a.cpu().numpy(), b) <= 5e-6
+    assert abs(res[0] - ref_res[0]) <= TOL and abs(res[2] - ref_res[2]) <= TOL
+    assert res[1] == ref_res[1] and res[3] == ref_res[3]
+    got = net.experiment_results
+    assert got["train_2target"] == ref_extra["train_2target"] and got["test_2target"] == ref_extra["test_2target"]
+    if hp["reverse"]:
+        assert abs(got["reverse"][0] - ref_extra["reverse"][0]) <= TOL and got["reverse"][1] == ref_extra["reverse"][1]
+    assert os.path.exists(os.path.join("models", "model.npz"))
+    # -load_model 1 with epochs 0: the stored weights reproduce the test numbers (TE:464-476)
+    hp2 = dict(hp, load_model=1.0, epochs=0)
+    net2, res2 = te.train_model(hp2)
+    assert abs(res2[2] - res[2]) <= 1e-6 and res2[3] == res[3]
+    stm.reseed(1030)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# data parallel: two ranks on one GPU, gloo rendezvous, HIP compute
+# ------------------------------------------------------------------------------------------------------------------
+
+_DP_SCRIPT = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+from scone_gcn_amd import synthetic_data_gen as g, trajectory_experiments as te, scone_trajectory_model as stm
+from scone_gcn_amd.complex import SimplicialComplex
+torch.cuda.set_device(0)
+if world > 1:
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+cx = g.random_SC_graph(1500)
+sc = SimplicialComplex(cx)
+paths = g.generate_random_walks(cx, m=37, seed=5, waypoint_pool=8, metric="euclid")
+flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=6)
+y = np.zeros((37, sc.max_degree, 1)); y[np.arange(37), choice, 0] = 1.0
+shifts, readout, _ = te.setup_from_complex(sc, "scone")
+inputs = [readout, last, flows]
+stm.reseed(1030)
+net = stm.Scone_GCN(1, 1e-2, 30, 5e-5, verbose=False)
+net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(37, int), model_type="scone")
+with torch.no_grad():
+    for w in net.weights:
+        w.mul_(12.0)
+mask = np.ones(37, int); mask[[1, 8, 30]] = 0            # 34 trajectories: 17 + 17, uneven slabs
+part = float(net.grad_step(inputs, y, mask, apply=False))
+grad = net._flat_g.cpu().numpy().copy()
+for _ in range(2):
+    net.grad_step(inputs, y, mask)                        # two optimiser steps: replicas must stay identical
+np.savez(out, grad=grad, part=part, w=net._flat_w.cpu().numpy())
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gradient_step_through_the_hip_path(tmp_path):
+    """Scone_GCN.grad_step under torch.distributed with TWO ranks (gloo rendezvous, both on GPU 0 -- the RCCL leg needs two
+    GPUs): the all-reduced flat gradient equals the single-process one (fp32 summation order differs between one and two
+    shards: <= 1e-6 of the largest entry), the ranks hold bit-identical gradients and weights after two optimiser steps, and
+    the local loss shares add up (STM:313-322 sharded per SURVEY section 8e)."""
+    _need_gpu()
+    script = tmp_path / "dp_rank.py"
+    script.write_text(_DP_SCRIPT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    one = subprocess.run([sys.executable, str(script), ROOT, "0", "1", port, str(tmp_path / "single.npz")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(tmp_path / ("rank%d.npz" % r))], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[1][-2000:]
+    ref = np.load(tmp_path / "single.npz")
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["grad"], r1["grad"]) and np.array_equal(r0["w"], r1["w"])
+    gmax = np.abs(ref["grad"]).max()
+    assert gmax > 1e-4
+    assert np.abs(r0["grad"] - ref["grad"]).max() <= 1e-6 * gmax
+    assert abs(float(r0["part"]) + float(r1["part"]) - float(ref["part"])) <= 1e-6 * max(1.0, abs(float(ref["part"])))
+    assert np.abs(r0["w"] - ref["w"]).max() <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# exact-split bf16 kernels vs the fp32-MFMA kernels, wide dynamic range
+# ------------------------------------------------------------------------------------------------------------------
+
+_AB_SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te
+from scone_gcn_amd.complex import SimplicialComplex
+cx = g.random_SC_graph(3000)
+sc = SimplicialComplex(cx)
+shifts, readout, _ = te.setup_from_complex(sc, "scone")
+plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+E = cx.n_edges
+rs = np.random.RandomState(11)
+res = {}
+for C in (32, 16):
+    S = 3
+    # every row mixes magnitudes from 1e-4 to 1e3 (and both signs): hi / mid / lo parts of the split all matter
+    mag = 10.0 ** rs.uniform(-4, 3, size=(S, E, 4, C))
+    x = (mag * rs.choice([-1.0, 1.0], size=mag.shape)).astype(np.float32)
+    aux = np.tanh(rs.randn(S, E, 4, C)).astype(np.float32)
+    W = [(10.0 ** rs.uniform(-3, 0, size=(C, C)) * rs.choice([-1.0, 1.0], size=(C, C))).astype(np.float32) for _ in range(3)]
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(aux).cuda()
+    Wt = [torch.from_numpy(w).cuda() for w in W]
+    out = plan.conv.forward([xt], Wt, C, "none")
+    dWs = [torch.zeros_like(w) for w in Wt]
+    dx = plan.conv.backward([xt], Wt, at, "tanh", True, dWs)
+    res["fwd%d" % C] = out.cpu().numpy(); res["dx%d" % C] = dx.cpu().numpy()
+    for k in range(3):
+        res["dW%d_%d" % (C, k)] = dWs[k].cpu().numpy()
+    if os.environ.get("SCN_F32_MFMA") is None:
+        res["x%d" % C], res["aux%d" % C] = x, aux
+        for k in range(3):
+            res["W%d_%d" % (C, k)] = W[k]
+        lo, up = shifts[0].device_csr(), shifts[1].device_csr()
+        res["lo_data"], res["lo_indices"], res["lo_indptr"] = lo.data, lo.indices, lo.indptr
+        res["up_data"], res["up_indices"], res["up_indptr"] = up.data, up.indices, up.indptr
+np.savez(sys.argv[2], **res)
+'''
+
+
+def test_exact_split_bf16_kernels_agree_with_the_fp32_mfma_kernels_on_wide_dynamic_range(tmp_path):
+    """The default C=32 / C=16 kernels evaluate fp32 products as six bf16 MFMAs on an exact three-way split; the fp32-MFMA
+    kernels they replaced stay behind SCN_F32_MFMA=1 (read once per process, hence two child processes).  On slabs whose
+    every row spans 1e-4 .. 1e3 both builds must agree with an fp64 evaluation to fp32 accuracy (relative to each output's
+    own sum of |terms|) -- a truncated split (bf16, or two of the three parts) fails this by orders of magnitude."""
+    _need_gpu()
+    import scipy.sparse as sp
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    outs = {}
+    for name, extra in (("bf16x3", {}), ("f32", {"SCN_F32_MFMA": "1"})):
+        env = dict(os.environ)
+        env.pop("SCN_F32_MFMA", None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / (name + ".npz"))], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(tmp_path / (name + ".npz"))
+    a, b = outs["bf16x3"], outs["f32"]
+    E = len(a["lo_indptr"]) - 1
+    lo = sp.csr_matrix((a["lo_data"], a["lo_indices"], a["lo_indptr"]), shape=(E, E)).astype(np.float64)
+    up = sp.csr_matrix((a["up_data"], a["up_indices"], a["up_indptr"]), shape=(E, E)).astype(np.float64)
+    for C in (32, 16):
+        x = a["x%d" % C].astype(np.float64)
+        W = [a["W%d_%d" % (C, k)].astype(np.float64) for k in range(3)]
+        S = x.shape[0]
+        flat = x.transpose(1, 0, 2, 3).reshape(E, -1)
+        g = [x, (lo @ flat).reshape(E, S, 4, C).transpose(1, 0, 2, 3), (up @ flat).reshape(E, S, 4, C).transpose(1, 0, 2, 3)]
+        ga = [np.abs(x), (abs(lo) @ np.abs(flat)).reshape(E, S, 4, C).transpose(1, 0, 2, 3),
+              (abs(up) @ np.abs(flat)).reshape(E, S, 4, C).transpose(1, 0, 2, 3)]
+        ref = sum(gk @ Wk for gk, Wk in zip(g, W))
+        scale = sum(gk @ np.abs(Wk) for gk, Wk in zip(ga, W))            # sum of |terms| of every output
+        for name in ("bf16x3", "f32"):
+            err = np.abs(outs[name]["fwd%d" % C] - ref) / scale
+            assert err.max() <= 8e-6, (name, C, err.max())
+        # backward: dx = (sum_k G_k W_k^T) * tanh'(aux) with G = gathered dz (symmetric shifts), dW_k = aux^T G_k
+        aux = a["aux%d" % C].astype(np.float64)
+        refdx = sum(gk @ Wk.T for gk, Wk in zip(g, W)) * (1.0 - aux ** 2)
+        sdx = sum(gk @ np.abs(Wk).T for gk, Wk in zip(ga, W))
+        for name in ("bf16x3", "f32"):
+            err = np.abs(outs[name]["dx%d" % C] - refdx) / sdx
+            assert err.max() <= 8e-6, (name, C, err.max())
+            for k in range(3):
+                refw = np.einsum("srnc,srnd->cd", aux, g[k])
+                sw = np.einsum("srnc,srnd->cd", np.abs(aux), ga[k])
+                errw = np.abs(outs[name]["dW%d_%d" % (C, k)] - refw) / sw
+                assert errw.max() <= 1e-4, (name, C, k, errw.max())       # fp32 accumulation over S*E*4 = 1e5 terms
+        # and the two builds against each other
+        assert (np.abs(a["fwd%d" % C] - b["fwd%d" % C]) / scale).max() <= 8e-6

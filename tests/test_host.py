@@ -231,3 +231,101 @@ def test_work_list_layout_and_square_detection(cx):
     assert ops._is_square_of(L1sq, L1) and not ops._is_square_of(L1, L1sq)
     lo, up = sc.scone_shifts()
     assert not ops._is_square_of(up, lo)
+
+
+def test_data_setup_returns_the_references_eleven_values(tmp_path, monkeypatch):
+    """TE:311: inputs_all, y_all, train_mask, test_mask, shifts, G_undir, E_lookup, nbrhoods, n_nbrs, target_nodes_all,
+    prefixes; under -flip_edges the flips come from the trainer's global stream reseeded with 1 (TE:214-219), the inputs are
+    X F (TE:292-296) and the prefixes still describe the stored (unflipped) flows."""
+    from scone_gcn_amd import dataset_io, scone_trajectory_model as stm, trajectory_experiments as te
+    monkeypatch.chdir(tmp_path)
+    cx = dataset_io.generate_dataset(150, 30, folder="d", holes=True)
+    hp = te.hyperparams(["prog", "-model", "scone"])
+    out = te.data_setup(hops=(1, 2), load=True, folder_suffix="d", hp=hp)
+    assert len(out) == 11
+    inputs_all, y_all, train_mask, test_mask, shifts, G, E_lookup, nbrhoods, n_nbrs, tn_all, prefixes = out
+    assert len(inputs_all) == 2 and len(shifts) == 2 and len(prefixes) == 30
+    assert len(G.nodes) == cx.n_nodes and len(G.edges) == cx.n_edges and G.degree[3] == len(G[3])
+    assert max(G.degree, key=lambda x: x[1])[1] == nbrhoods.shape[1]                       # TE:273
+    assert E_lookup[tuple(cx.edges[5])] == 5
+    last = inputs_all[0][1]
+    assert np.array_equal(n_nbrs, [len(G[n]) for n in last])
+    X = inputs_all[0][2]
+    for i in (0, 7, 29):                                                                   # prefixes <-> flows (SDG:299-344)
+        assert prefixes[i][-1] == last[i]
+        assert np.array_equal(g.paths_to_flows(cx, [prefixes[i]]).todense()[0], np.asarray(X)[i])
+    # Bconds object answers like the closure of TE:298-303
+    Bc = inputs_all[0][0]
+    B1 = g.incidence_matrices(cx)[0].toarray()
+    n0 = int(last[0])
+    ref = np.concatenate([B1, np.zeros((1, B1.shape[1]))])[nbrhoods[n0]]
+    assert np.array_equal(Bc(n0), ref)
+    # prefixes reconstructed from the flows when the folder has no prefixes file
+    os.remove("trajectory_data_1hop_d/prefixes.npz")
+    assert te.data_setup(hops=(1,), load=True, folder_suffix="d", hp=hp)[10] == prefixes
+    # -flip_edges: global stream reseeded with 1, flips drawn from it, weights continue it
+    hpf = te.hyperparams(["prog", "-flip_edges", "1"])
+    outf = te.data_setup(hops=(1,), load=True, folder_suffix="d", hp=hpf)
+    rs = np.random.RandomState(1)
+    flips = rs.choice([1, -1], size=cx.n_edges, replace=True, p=[0.8, 0.2])
+    assert np.array_equal(np.asarray(outf[0][0][2])[:, :, 0], np.asarray(X)[:, :, 0] * flips[None, :])
+    assert stm._RNG.randn() == rs.randn()
+    assert outf[10] == prefixes
+    stm.reseed(1030)
+
+
+def test_probed_bcond_closure_yields_the_readout_tables_of_the_native_object(cx):
+    """A plain closure n -> B1_jax[nbrhoods[n]] (TE:298-303) is probed by calling it; the tables built from the answers give the
+    same logits as the native Bconds tables (NumPy evaluation of the readout formula, TE:151)."""
+    from scone_gcn_amd.complex import ProbedBconds, adopt_bconds, adopt_shift, identity_layout
+    sc = SimplicialComplex(cx, reorder=False)
+    B1 = g.incidence_matrices(cx)[0].toarray()
+    B1x = np.concatenate([B1, np.zeros((1, B1.shape[1]))])
+    nb = sc.nbrhoods
+    fn = lambda n: B1x[nb[n]]
+    lay = identity_layout((1, cx.n_edges, 1))
+    pb = adopt_bconds(fn, cx.n_edges, lay)
+    assert adopt_bconds(fn, cx.n_edges, lay) is pb and isinstance(pb, ProbedBconds)
+    last = np.array([5, 17, 5, 200, 17])
+    rows = pb.prepare(last)
+    assert rows.tolist() == [0, 1, 0, 2, 1] and pb.version == 1
+    assert pb.prepare(np.array([17])).tolist() == [1] and pb.version == 1                  # nothing new: no rebuild
+    ptr, edge, sign, edge_nodes = pb.incidence_tables()
+    rs = np.random.RandomState(0)
+    h = rs.randn(cx.n_edges)
+    for r, n in zip(rows, last):
+        got = np.array([0.0 if v < 0 else float(sign[ptr[v]:ptr[v + 1]] @ h[edge[ptr[v]:ptr[v + 1]]]) for v in pb.nbrhoods[r]])
+        assert np.allclose(got, fn(n) @ h, atol=1e-6)
+    for e in range(cx.n_edges):                                                            # endpoints: -2 = not probed
+        ks = [k for k in edge_nodes[e] if k >= 0]
+        for k in ks:
+            assert e in edge[ptr[k]:ptr[k + 1]]
+    bad = np.zeros((2, cx.n_edges))
+    bad[0, :2] = 1.0                                    # edge 0 in two different rows with the SAME sign: not an incidence matrix
+    bad[1, 0] = 1.0
+    pbad = ProbedBconds(lambda n: bad, cx.n_edges, lay)
+    pbad.prepare([0])
+    with pytest.raises(TypeError):
+        pbad.incidence_tables()
+    with pytest.raises(TypeError):
+        ProbedBconds(lambda n: np.ones((3, 5)), cx.n_edges, lay).prepare([0])            # wrong row length
+    # dense shifts are wrapped once, in the caller's order
+    L = (g.incidence_matrices(cx)[0].T @ g.incidence_matrices(cx)[0]).toarray()
+    sh = adopt_shift(L, lay, 1, 1)
+    assert adopt_shift(L, lay, 1, 1) is sh and np.array_equal(sh.toarray(), L) and np.array_equal(sh.device_csr().toarray(), L)
+
+
+def test_bench_refuses_a_rank_count_it_cannot_have():
+    """`bench.py --gpus N` never runs a silent single-GPU job: without N visible GPUs it exits non-zero before touching
+    anything, and a launcher environment whose WORLD_SIZE differs from --gpus is an error too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 64:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True)
+        assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "2", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr

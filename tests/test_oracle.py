@@ -217,3 +217,51 @@ def test_draw_batch_mask_follows_reference_stream():
     tm = np.array([1] * 8 + [0] * 2)
     bm = so.draw_batch_mask(rs, 10, 4, tm)
     assert bm.dtype == bool and bm.sum() <= 4 and not bm[8:].any()
+
+
+def test_sparse_fp32_torch_restatement_matches_the_fp64_oracle(cfg1):
+    """oracle/torch_sparse.py (the CPU baseline B2 of bench.py: fp32, torch.sparse_csr shifts, autograd) against the fp64
+    NumPy oracle with its hand-derived backward."""
+    import warnings
+    import scipy.sparse as sp
+    torch = pytest.importorskip("torch")
+    from oracle import torch_sparse as ts
+    warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
+    B1, B2 = cfg1["B1"], cfg1["B2"]
+    sel = np.arange(10)
+    L_lo, L_up = so.scone_shifts(B1, B2)
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    rs = np.random.RandomState(3)
+    w = [0.2 * rs.randn(*s) for s in so.weight_shapes(1, [(3, 8)] * 3, 1)]
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, so.make_Bconds(B1, nb), last, X, y, np.ones(10, int), 5e-5)
+    Sl, Su = ts.csr_tensor(sp.csr_matrix(L_lo)), ts.csr_tensor(sp.csr_matrix(L_up))
+    loss, grads = ts.loss_and_grad([torch.tensor(a, dtype=torch.float32) for a in w], Sl, Su, Sl, Su,
+                                   ts.make_inc_rows(sp.csr_matrix(B1), nb), last, torch.tensor(X, dtype=torch.float32),
+                                   torch.tensor(y, dtype=torch.float32), 5e-5)
+    assert abs(loss - ref_loss) < 1e-5
+    for a, b in zip(grads, ref_g):
+        assert np.abs(a.numpy() - b).max() < 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_two_target_accuracy_restatement(cfg1):
+    """STM:73-108 on fixed log-probabilities: the cached random targets differ from the PREDICTED choice afterwards (the
+    reference's quirk), ties count one half, and the second call reuses the draw."""
+    rs = np.random.RandomState(5)
+    N, D = 12, cfg1["D"]
+    n_nbrs = rs.randint(2, D, size=N)
+    preds = np.log(rs.dirichlet(np.ones(D), size=N))[:, :, None]
+    y = so.onehot_targets(rs.randint(0, 2, size=N), D)
+    mask = np.array([1, 1, 0, 1, 0, 1, 1, 1, 0, 1, 1, 0])
+    acc, rt = so.two_target_accuracy_from_preds(preds, y, mask, n_nbrs, np.random.RandomState(9))
+    p = preds.copy()
+    for i in range(N):
+        p[i, n_nbrs[i]:] = -100
+    pc = np.argmax(p[mask == 1], axis=1).reshape(-1)
+    for i in range(N):
+        assert rt[i] != pc[min(i, len(pc) - 1)] and 0 <= rt[i] < n_nbrs[i]
+    t = p[np.arange(N), np.argmax(y, axis=1).reshape(N), 0][mask == 1]
+    r = p[np.arange(N), rt, 0][mask == 1]
+    assert acc == (np.sum(t > r) + 0.5 * np.sum(t == r)) / mask.sum()
+    acc2, rt2 = so.two_target_accuracy_from_preds(preds, y, mask, n_nbrs, np.random.RandomState(1), random_targets=rt.copy())
+    assert acc2 == acc and np.array_equal(rt, rt2)
