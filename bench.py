@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=4096, help="trajectories per optimiser step over ALL ranks")
     ap.add_argument("--per-gpu-batch", type=int, default=0,
                     help="> 0: weak scaling instead -- this many trajectories per GPU (global batch = N x this)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="trajectories in the sparse CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="trajectories in the sparse CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-sample", type=int, default=4, help="trajectories of the full-size oracle comparison (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0: headline only (no other configs, no SpMM, no skipping modes)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")

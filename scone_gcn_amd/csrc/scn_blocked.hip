@@ -321,8 +321,16 @@ __device__ __forceinline__ BlockMeta load_block_c32(const PlanDev& P, int b, con
 //    kernels are VALU-issue bound (profiles/r01_pmc_fwd_bwd_c32_bf16.txt), so instruction count is what matters;
 //  * all 2*NQ LDS reads of an entry pair are issued before the first FMA and the next pair's slots / values are fetched
 //    behind them: left to itself hipcc serialises read -> s_waitcnt lgkmcnt(0) -> use under register pressure.
-template <int NQ, bool DUAL = true>     // DUAL = false: operator with one value array, gu is left untouched
-__device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, int twu, const uint32_t (&cb)[NQ],
+template <int NQ>
+__device__ __forceinline__ void read_self_c32(const SmemC32& sm, int row, const uint32_t (&cb)[NQ], f32x4 (&gs)[NQ]) {
+    const uint32_t slot = sm.self[row];
+    const uint32_t enc = (slot << 9) | ((slot & 3) << 5);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) gs[q] = *(const f32x4*)(sm.buf0 + (cb[q] ^ enc));
+}
+
+template <int NQ, bool DUAL = true, bool SELF = true>     // DUAL = false: operator with one value array, gu is left untouched
+__device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, int tw, int twu, const uint32_t (&cb)[NQ],   // SELF = false: gs is left untouched (read_self_c32 later)
                                            f32x4 (&gs)[NQ], f32x4 (&gl)[NQ], f32x4 (&gu)[NQ]) {
     const char* lds = sm.buf0;
     const int rb = row * w;                                   // w is even: entry pairs are 4-byte aligned
@@ -333,7 +341,7 @@ __device__ __forceinline__ void gather_c32(const SmemC32& sm, int row, int w, in
         const uint32_t enc = (slot << 9) | ((slot & 3) << 5);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            gs[q] = *(const f32x4*)(lds + (cb[q] ^ enc));
+            if (SELF) gs[q] = *(const f32x4*)(lds + (cb[q] ^ enc));
             gl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (DUAL) gu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -1653,7 +1661,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_kernel(PlanDev P, const
 // the VALU instruction count (5.5 per split value) matters as much as the MFMA count.
 // ------------------------------------------------------------------------------------------------
 constexpr int B32_WFRAG_BYTES = 3 * 2 * 3 * 64 * 16;      // [segment][k-step][split][lane] x 8 bf16
-static_assert(B32_WFRAG_BYTES <= BK_WAVES * 16 * T32_STRIDE * 4, "weight fragments take the place of the fp32 kernel's patches");
+static_assert(B32_WFRAG_BYTES + 2048 <= 160 * 1024 - (2 * BK_SRC * 512 + BK_ELL_CAP * 10 + BK_SRC * 4 + BK_R + 16), "weight + selection fragments fit behind the staging buffers");
 
 // EXT0 (see fwd_c32_w16_kernel): segment 0 of G is the upstream gradient itself (DZ0, own rows from HBM), the staged tensor
 // DZ is S^T dz: segment 1 its own row, segment 2 its gathered shift (S^T)^2 dz.
@@ -1695,17 +1703,18 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         *(bf16x8*)(base + 1024) = sp.mid;
         *(bf16x8*)(base + 2048) = sp.lo;
     }
-    // selection fragments: k-step t, B[k = 8h + j][n = p] = (p == 16h + 8t + j)
-    bf16x8 Isel[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    // selection fragments: k-step t, B[k = 8h + j][n = p] = (p == 16h + 8t + j); kept in LDS behind the weight fragments
+    // (two lane-linear B fragments; read back right where a transpose needs them -- registers are what this kernel lacks)
+    char* isel = wfrag + B32_WFRAG_BYTES;
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 6, l = threadIdx.x & 63, pp = l & 31, hh = l >> 5;
         u32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c0 = 16 * h + 8 * t + 2 * i;
-            v[i] = (p == c0 ? 0x3F80u : 0u) | (p == c0 + 1 ? 0x3F800000u : 0u);
+            const int c0 = 16 * hh + 8 * t + 2 * i;
+            v[i] = (pp == c0 ? 0x3F80u : 0u) | (pp == c0 + 1 ? 0x3F800000u : 0u);
         }
-        Isel[t] = __builtin_bit_cast(bf16x8, v);
+        *(u32x4*)(isel + t * 1024 + l * 16) = v;
     }
     f32x16 dWacc[3];
 #pragma unroll
@@ -1718,7 +1727,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) cqs[q] = (uint32_t)((n * 8 + h * 4 + q) ^ (n >> 1)) << 4;
     const size_t slab_bytes = (size_t)n_cols * (PAIR ? 256 : PIECE);
-    const bool second = PAIR && (((lane >> 2) ^ wave) & 1);       // this lane's LDS-DMA chunks come from slab B (see goff)
+    const bool second = PAIR && (((lane >> 2) ^ wave) & 1);       // this lane's LDS-DMA chunks come from slab B (see dma_k)
     if (listed || slab0 < slab1)
     SCN_UNIT_BEGIN()
         wait_all_and_barrier();
@@ -1727,49 +1736,57 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
         const int tw = P.tile_w[b * BK_WAVES + wave];
         const int twu = EXT0 ? 0 : P.tile_wu[b * BK_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
-        uint32_t goff[NDMA];
+        // LDS-DMA instruction k of this wave moves chunks c = (k * 8 + wave) * 64 + lane: slot = 2 * (k * 8 + wave) + (lane >> 5),
+        // position lane & 31.  The swizzled source chunk only depends on slot & 3 = ((wave & 1) << 1) | (lane >> 5), i.e. it is ONE
+        // lane constant for every k, and the slot's source row comes from LDS at a lane constant + 64 * k: no per-k offsets in
+        // registers.  PAIR: virtual chunk n*8 + q*4 + g <- slab q, chunk n*4 + g; q = bit 2 of d = ((lane>>2) ^ wave) & 1 for every k.
         const int total = m.nsrc * CPP;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int c = (i * BK_WAVES + wave) * 64 + lane;
-            const int slot = c / CPP, pos = c % CPP;
-            const int d = swz32(slot, pos);                      // PAIR: virtual chunk n*8 + q*4 + g <- slab q, chunk n*4 + g;
-            goff[i] = c >= total ? 0u                            // q = bit 2 of d = ((lane>>2) ^ wave) & 1 for every i
-                      : (PAIR ? (uint32_t)sm.srcrows[slot] * 256 + ((d >> 3) * 4 + (d & 3)) * 16
-                              : (uint32_t)sm.srcrows[slot] * PIECE + d * 16);
-        }
+        const int dq = swz32(((wave & 1) << 1) | (lane >> 5), lane & 31);
+        const uint32_t dchunk = PAIR ? (uint32_t)(((dq >> 3) * 4 + (dq & 3)) * 16) : (uint32_t)(dq * 16);
+        const int32_t* my_src = sm.srcrows + 2 * wave + (lane >> 5);          // + 16 * k
+        auto dma_k = [&](int k, const char* Xs, char* buf) {
+            const int base = (k * BK_WAVES + wave) * 64;
+            if (base + lane < total) {
+                const uint32_t off = (uint32_t)my_src[16 * k] * (PAIR ? 256u : (uint32_t)PIECE) + dchunk;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xs + off),
+                                                 (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+            }
+        };
         const int n_vis = PAIR ? (n_it + 1) >> 1 : n_it;          // visits: slabs, or slab pairs
         auto slab_of = [&](int vis, int q) {                     // q-th slab of a visit (the lone last slab stands in for its pair)
             if (!PAIR) return SLAB_AT(vis);
             return SLAB_AT(2 * vis + q < n_it ? 2 * vis + q : 2 * vis);
         };
         auto src_base = [&](int vis) {
+            if (!PAIR) {    // wave-uniform: say so, and the LDS-DMA takes (SGPR base + 32-bit lane offset) instead of a 64-bit VGPR address
+                const uint64_t v = (uint64_t)((const char*)DZ + (size_t)slab_of(vis, 0) * slab_bytes);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                return (const char*)(((uint64_t)hi << 32) | lo);
+            }
             return (const char*)DZ + (size_t)slab_of(vis, second ? 1 : 0) * slab_bytes;
         };
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int base = (i * BK_WAVES + wave) * 64;
-            if (base + lane < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_base(0) + goff[i]),
-                                                 (__attribute__((address_space(3))) void*)(sm.buf(0) + base * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < NDMA; ++i) dma_k(i, src_base(0), sm.buf(0));
         const int rows_left = m.rows - wave * 8;
+        f32x4 G[3][4];
         for (int it = 0; it < n_vis; ++it) {
-            const int slab = slab_of(it, PAIR ? p >> 4 : 0);      // PAIR: lanes p >= 16 hold slab B's channels
+            const int slab = slab_of(it, PAIR ? p >> 4 : 0);          // PAIR: lanes p >= 16 hold slab B's channels
             const bool lane_live = !PAIR || p < 16 || 2 * it + 1 < n_it;
-            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * CH;
-            const float* ap = aux + (rows_left > 0 ? tuni : 0);
-            float* dp = dx && lane_live ? dx + tuni : nullptr;
-            const int L0 = (PAIR ? p & 15 : p) + 4 * CH * h;
+            const uint32_t bufbit = (uint32_t)((it & 1) << 16);
+            const uint32_t cbs[4] = {cqs[0] | bufbit, cqs[1] | bufbit, cqs[2] | bufbit, cqs[3] | bufbit};
             STAMP_START();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP_ADD(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             STAMP_ADD(1);
-            // the tile's 16 aux values and the first weight fragments are requested before the gather so that their
-            // latency (HBM / LDS) is covered by it; they are issued ahead of the next slab's LDS-DMA, so waiting for them
-            // later leaves the DMA in flight
+            const size_t tuni = (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * CH;
+            const float* ap = aux + (rows_left > 0 ? tuni : 0);
+            float* dp = dx && lane_live ? dx + tuni : nullptr;
+            const int L0 = (PAIR ? p & 15 : p) + 4 * CH * h;
+            // the tile's 16 aux values and the first weight fragments are requested before the gather so that their latency
+            // (HBM / LDS) is covered by it; they are issued ahead of the next slab's LDS-DMA, so waiting for them later leaves
+            // the DMA in flight
             float a[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1777,44 +1794,44 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                 const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * CH : 0];
                 a[r] = ok ? v : 0.f;
             }
+            constexpr int GSEQ[3] = {1, 2, 0};                           // segment order
             bf16x8 wn[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wfrag + lane * 16 + i * 1024);
+            for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wfrag + lane * 16 + ((GSEQ[0] * 2 + 0) * 3 + i) * 1024);
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 G[3][4];
-            {
-                const uint32_t bufbit = (uint32_t)((it & 1) << 16);
-                const uint32_t cb[4] = {cqs[0] | bufbit, cqs[1] | bufbit, cqs[2] | bufbit, cqs[3] | bufbit};
-                if (EXT0) {
-                    const float* g0 = DZ0 + (((size_t)slab * n_rows + m.row0 + rtc) * BK_NS + n) * 32 + 16 * h;
+            // ---------------- GATHER: G[1], G[2]; the identity segment is four LDS reads, made right before it is needed, so
+            // it never shares the register file with the other two
+            if (EXT0) {
+                const float* g0 = DZ0 + (((size_t)slab * n_rows + m.row0 + rtc) * BK_NS + n) * 32 + 16 * h;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) G[0][q] = *(const f32x4*)(g0 + 4 * q);
-                    f32x4 unused[4];
-                    gather_c32<4, false>(sm, rtc, m.w, tw, 0, cb, G[1], G[2], unused);
-                } else {
-                    __builtin_amdgcn_s_setprio(3);
-                    gather_c32<4>(sm, rtc, m.w, tw, twu, cb, G[0], G[1], G[2]);
-                    __builtin_amdgcn_s_setprio(1);
-                }
+                for (int q = 0; q < 4; ++q) G[0][q] = *(const f32x4*)(g0 + 4 * q);
+                f32x4 unused[4];
+                gather_c32<4, false>(sm, rtc, m.w, tw, 0, cbs, G[1], G[2], unused);
+            } else {
+                __builtin_amdgcn_s_setprio(3);
+                gather_c32<4, true, false>(sm, rtc, m.w, tw, twu, cbs, G[0], G[1], G[2]);
+                __builtin_amdgcn_s_setprio(1);
             }
             STAMP_ADD(2);
-            // dgrad + transpose: 6 (segment, k-step) groups of 6 + 3 MFMAs; the 8 LDS-DMA instructions of the next slab ride in
-            // the first four groups
-            f32x16 acc = zero16;
-            f32x16 T[3];
-            const bool more = it + 1 < n_vis;
-            const char* Xn = src_base(more ? it + 1 : it);
-            char* nbuf = sm.buf((it + 1) & 1);
+            // ---------------- CONTRACT
+            const int vdma = it + 1;                                     // the visit whose slab this contraction stages
+            const bool more = vdma < n_vis;
+            const char* Xn = src_base(more ? vdma : it);
+            char* nbuf = sm.buf(vdma & 1);
             auto side = [&](int k) {
-                if (k < NDMA) {
-                    const int base = (k * BK_WAVES + wave) * 64;
-                    if (more && base + lane < total)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xn + goff[k]),
-                                                         (__attribute__((address_space(3))) void*)(nbuf + base * 16), 16, 0, 0);
-                }
+                if (k < NDMA && more) dma_k(k, Xn, nbuf);
             };
+            // Per segment g: [transpose + dgrad] over its two k-steps, then straight into dW_g.  The transpose keeps the three
+            // parts of the split in THREE accumulators (T_hi, T_mid, T_lo = hi / mid / lo of G_g, one channel per lane): each
+            // holds exactly bf16-representable values, so the B operand of the weight gradient is a pack (v_perm, one per two
+            // values) instead of a second split3 of their sum.
+            f32x16 acc;
+            Split3 At[2];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
+            for (int u = 0; u < 3; ++u) {
+                const int g = GSEQ[u];
+                if (u == 2 && !EXT0) read_self_c32<4>(sm, rtc, cbs, G[0]);
+                f32x16 Th, Tm, Tl;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float x8[8];
@@ -1822,11 +1839,13 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     for (int j = 0; j < 8; ++j) x8[j] = G[g][2 * t + (j >> 2)][j & 3];
                     const Split3 zs = split3(x8);
                     const bf16x8 wh = wn[0], wm = wn[1], wl = wn[2];
-                    const int k0 = (g * 2 + t) * 2;                          // two LDS-DMA side slots per group (8 used)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, wh, acc, 0, 0, 0);
-                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, Isel[t], t == 0 ? zero16 : T[g], 0, 0, 0);
-                    if (g * 2 + t < 5) {                                     // next group's fragments, one group ahead
-                        const char* wb = wfrag + ((g * 2 + t + 1) * 3) * 1024 + lane * 16;
+                    const bf16x8 It = *(const bf16x8*)(isel + t * 1024 + lane * 16);
+                    const int k0 = (u * 2 + t) * 2;                          // two LDS-DMA side slots per group (8 used)
+                    Tl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, It, t == 0 ? zero16 : Tl, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.lo, wh, (u == 0 && t == 0) ? zero16 : acc, 0, 0, 0);
+                    if (u * 2 + t < 5) {                                     // next group's fragments, one group ahead
+                        const int un = (u * 2 + t + 1) >> 1, tn = (u * 2 + t + 1) & 1;
+                        const char* wb = wfrag + ((GSEQ[un] * 2 + tn) * 3) * 1024 + lane * 16;
 #pragma unroll
                         for (int i = 0; i < 3; ++i) wn[i] = *(const bf16x8*)(wb + i * 1024);
                     }
@@ -1834,50 +1853,57 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     side(k0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wl, acc, 0, 0, 0);
                     side(k0 + 1);
+                    Tm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, It, t == 0 ? zero16 : Tm, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wm, acc, 0, 0, 0);
-                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, Isel[t], T[g], 0, 0, 0);
+                    Th = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, It, t == 0 ? zero16 : Th, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.mid, wh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wm, acc, 0, 0, 0);
-                    T[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, Isel[t], T[g], 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zs.hi, wh, acc, 0, 0, 0);
                 }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            STAMP_ADD(3);
-            // dW A fragments from the aux tile (k-step t <-> points pt(8t + j, h)), then dX = acc * act'(aux)
-            Split3 At[2];
+                if (u == 0) {                                         // dW A fragments from the aux tile (k-step t <-> points pt(8t + j, h))
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float x8[8];
+                    for (int t = 0; t < 2; ++t) {
+                        float x8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x8[j] = a[8 * t + j];
-                At[t] = split3(x8);
-            }
+                        for (int j = 0; j < 8; ++j) x8[j] = a[8 * t + j];
+                        At[t] = split3(x8);
+                    }
+                }
+                if (u == 2) {
+                    __builtin_amdgcn_s_setprio(0);
+                    STAMP_ADD(3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(ACT, a[r]);
-            // dW_g += aux^T T_g; the 16 dx stores ride inside the chains
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
+                    for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(ACT, a[r]);   // dX = acc * act'(aux)
+                }
+                // dW_g += aux^T T_g
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float x8[8];
+                    u32x4 ph, pm, pl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x8[j] = T[g][8 * t + j];
-                    const Split3 bs = split3(x8);
+                    for (int i = 0; i < 4; ++i) {
+                        ph[i] = pack_hi16(Th[8 * t + 2 * i], Th[8 * t + 2 * i + 1]);
+                        pm[i] = pack_hi16(Tm[8 * t + 2 * i], Tm[8 * t + 2 * i + 1]);
+                        pl[i] = pack_hi16(Tl[8 * t + 2 * i], Tl[8 * t + 2 * i + 1]);
+                    }
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, ph), bm = __builtin_bit_cast(bf16x8, pm),
+                                 bl = __builtin_bit_cast(bf16x8, pl);
                     const Split3& at = At[t];
-                    const int k0 = (g * 2 + t) * 3;                       // 18 store slots, 16 used
-                    auto store = [&](int r) {
-                        if (dp && r < 16 && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
+                    auto store = [&](int r) {                            // only in the last segment: acc is complete there
+                        if (u == 2 && dp && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
                     };
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bs.hi, dWacc[g], 0, 0, 0);
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.lo, dWacc[g], 0, 0, 0);
-                    store(k0);
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bs.mid, dWacc[g], 0, 0, 0);
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bs.hi, dWacc[g], 0, 0, 0);
-                    store(k0 + 1);
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.mid, dWacc[g], 0, 0, 0);
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bs.hi, dWacc[g], 0, 0, 0);
-                    store(k0 + 2);
+                    const int r0 = 8 * t;
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bh, dWacc[g], 0, 0, 0);
+                    store(r0);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bl, dWacc[g], 0, 0, 0);
+                    store(r0 + 1); store(r0 + 2);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bm, dWacc[g], 0, 0, 0);
+                    store(r0 + 3);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.mid, bh, dWacc[g], 0, 0, 0);
+                    store(r0 + 4); store(r0 + 5);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bm, dWacc[g], 0, 0, 0);
+                    store(r0 + 6);
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.hi, bh, dWacc[g], 0, 0, 0);
+                    store(r0 + 7);
                 }
             }
             STAMP_ADD(4);
@@ -2526,8 +2552,8 @@ bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz
 }
 
 static size_t bwd_lds(int cd, int c_aux) {
-    if (c_aux == 32) return smem_bytes_c32(B32_WFRAG_BYTES);   // (>= the fp32 variant's smem_bytes(512) + patches)
-    if (c_aux == 16) return std::max(smem_bytes_c32(B32_WFRAG_BYTES), smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4));
+    if (c_aux == 32) return smem_bytes_c32(B32_WFRAG_BYTES + 2048);   // weight + selection fragments (>= the fp32 variant's smem_bytes(512) + patches)
+    if (c_aux == 16) return std::max(smem_bytes_c32(B32_WFRAG_BYTES + 2048), smem_bytes(256, BK_WAVES * 2 * 16 * T16_STRIDE * 4));
     return smem_bytes(BK_NS * cd * 4, 16);
 }
 
@@ -2683,7 +2709,7 @@ bool blocked_power_supported(const scn_conv_s* c, int ns, int ch) { return power
 size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch) {
     if (!blocked_power_supported(c, ns, ch)) return 0;
     dim3 grid;
-    launch_grid(c, n_slabs, smem_bytes_c32(B32_WFRAG_BYTES), grid);
+    launch_grid(c, n_slabs, smem_bytes_c32(B32_WFRAG_BYTES + 2048), grid);
     return (size_t)grid.x * grid.y * 32 * 3 * 32 * sizeof(float);
 }
 
@@ -2717,7 +2743,7 @@ int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const fl
     PlanDev P = c->plan.dev;
     const WorkList wl{0, nullptr, nullptr, nullptr};
     dim3 grid;
-    const size_t lds = smem_bytes_c32(B32_WFRAG_BYTES);
+    const size_t lds = smem_bytes_c32(B32_WFRAG_BYTES + 2048);
     launch_grid(c, n_slabs, lds, grid);
     P.assign = balanced_assignment(c, grid.x);
     const int nr = c->n_rows, nc = c->g[0].n_cols;

@@ -84,7 +84,8 @@ constexpr int BK_R = 8 * BK_WAVES;   // output rows per block (upper bound; 8 pe
 constexpr int BK_SRC = 128;     // staged source pieces per block (upper bound)
 constexpr int BK_NS = 4;        // trajectories per slab the blocked kernels are built for
 constexpr int BK_THREADS = 64 * BK_WAVES;
-constexpr int BK_ELL_CAP = 1360;  // ELL entries (rows-in-block x padded width) a block may carry
+constexpr int BK_ELL_CAP = 1152;  // ELL entries (rows-in-block x padded width) a block may carry (64 rows x 18; 4 % of the blocks of the
+                                  // benchmark complex are cut a few rows short by it: the 2 KB go to the backward's selection fragments)
 
 // device view passed to kernels by value
 struct PlanDev {

@@ -982,6 +982,8 @@ def micro_batch_size(n_rows_total, widths, n, ns=NS, budget_bytes=None, device=N
     per_sample = 4.0 * n_rows_total * (sum(widths) + 2 * max(widths))
     mb_max = int(budget_bytes // max(per_sample, 1.0))
     mb_max = max(ns, min(mb_max, 16384) // ns * ns)
+    if mb_max >= 64:
+        mb_max = mb_max // 64 * 64          # whole groups of 16 slabs: what the kernels' slab grouping and grid splits are tuned for
     n_pad = pad_count(n, ns)
     n_chunks = -(-n_pad // mb_max)
     return pad_count(-(-n_pad // n_chunks), ns)

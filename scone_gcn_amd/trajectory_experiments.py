@@ -260,14 +260,17 @@ def train_model(hp=None):
         scone.two_target_accuracy(shifts, inputs_1hop, y_1hop, test_mask, n_nbrs)
     scone.test(inputs_1hop, y_1hop, test_mask, n_nbrs)
     print('2-target accs:', train_2target, test_2target)
-    results = {"train_2target": train_2target, "test_2target": test_2target}
+    results = {"train_2target": train_2target, "test_2target": test_2target,
+               "log_probs": scone._predict(scone.weights, inputs_1hop).cpu().numpy()}      # final predictions, kept for inspection
     if hp['reverse']:                                                      # TE:497-504
         from .dataset_io import load_reverse
         rev_flows_in, rev_targets_1hop, rev_last_nodes = load_reverse('trajectory_data_1hop_' + hp['data_folder_suffix'])
         rev_n_nbrs = np.asarray([len(G_undir[n]) for n in rev_last_nodes])                # TE:501
         print('Reverse experiment:')
         # (as in the reference, the reversed flows are fed as stored -- NOT multiplied by F under -flip_edges, TE:499-504)
-        results["reverse"] = scone.test([inputs_1hop[0], rev_last_nodes, rev_flows_in], rev_targets_1hop, test_mask, rev_n_nbrs)
+        rev_inputs = [inputs_1hop[0], rev_last_nodes, rev_flows_in]
+        results["reverse"] = scone.test(rev_inputs, rev_targets_1hop, test_mask, rev_n_nbrs)
+        results["reverse_log_probs"] = scone._predict(scone.weights, rev_inputs).cpu().numpy()
     scone.experiment_results = results
     return scone, (train_loss, train_acc, test_loss, test_acc)
 
