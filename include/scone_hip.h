@@ -226,7 +226,8 @@ int scn_clear_list(scn_conv_t conv, int32_t ns, int32_t channels, float* tensor,
 
 /* First layer (c_in = 1) fast path.
  * scn_conv_forward_first = scn_conv_forward for one 1-channel input, which also stores the shifted input
- *   y[n_slabs][n_rows][ns][3] = (x, S_val0 x, S_val1 x)  -- the three scalars per point the kernel forms anyway.
+ *   y[n_slabs][n_rows][ns][4] = (x, S_val0 x, S_val1 x, 0)  -- the three scalars per point the kernel forms anyway, as
+ *   16-byte records.
  * scn_conv_dw_first: weight gradient of that layer (no input gradient) with the shift on the 1-channel side,
  *   dW_slot[0][c] += sum_p y[p][slot] * dz[p][c]   (= what jax.grad of TE:144-149 yields for weights[0:3], STM:307):
  *   dz is read exactly once, coalesced.  Pass the y saved by the forward, or y = NULL and x: it is then recomputed into
@@ -241,6 +242,20 @@ size_t scn_conv_dw_first_workspace(scn_conv_t conv, int32_t n_slabs, int32_t ns,
 int scn_conv_dw_first(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x, const float* y, const float* dz,
                       int32_t c_dz, float* const* dW, void* workspace, size_t workspace_bytes,
                       const scn_work_list* wl /* NULL: dense; a list needs y */, void* stream);
+
+/* Backward of the layer that FOLLOWS the first one, fused with the first layer's weight gradient (what jax.grad of TE:144-149
+ * yields for weights[0:6], STM:307, in one pass):
+ *   this layer :  dW[slot] += aux^T G_slot                       (as scn_conv_backward; aux = the first layer's output)
+ *   first layer:  dW_first[slot][0][c] += sum_p y[p][slot] * dx[p][c],   dx = (sum_slots G_slot W_slot^T) * act'(aux)
+ * dx -- the gradient w.r.t. the first layer's pre-activation, whose only consumer is that weight gradient -- stays in
+ * registers and is never written: no [n_slabs][n_rows][ns][channels] tensor, no second pass over it.
+ * `conv_t` as in scn_conv_backward; y from scn_conv_forward_first; channels = 32 (SCN_ERR_UNSUPPORTED / workspace 0
+ * otherwise: use scn_conv_backward + scn_conv_dw_first).  A work list names the items of dz's support, as usual. */
+size_t scn_conv_backward_fused_first_workspace(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t channels);
+int scn_conv_backward_fused_first(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, const float* dz, const float* const* W,
+                                  const float* aux, int32_t channels, int32_t act, const float* y, float* const* dW,
+                                  float* const* dW_first, void* workspace, size_t workspace_bytes,
+                                  const scn_work_list* wl /* NULL: dense */, void* stream);
 
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)

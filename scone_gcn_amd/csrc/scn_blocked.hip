@@ -20,6 +20,7 @@
 #include <cstring>
 #include <numeric>
 #include <type_traits>
+#include <utility>
 
 #include "scn_internal.h"
 
@@ -456,6 +457,7 @@ __device__ __forceinline__ void block_range(int n_blocks, int& first, int& last,
 // 16 waves per workgroup (no MFMA, few registers): thread = (row, 16-byte chunk), two items per thread;
 // results are stored one slab late so the per-slab vmcnt(0) never waits on fresh stores.
 // ------------------------------------------------------------------------------------------------
+constexpr int Y_STRIDE = 4;      // floats per point of the shifted first-layer input y = (x, S_lo x, S_up x, 0): 16-byte records
 constexpr int SP_THREADS = 1024;
 constexpr int SP_ITEMS = 2;           // BK_R * 32 chunks / SP_THREADS
 constexpr int SP_SLAB_GROUP = 8;      // slabs a workgroup processes per visit of a block
@@ -1425,9 +1427,10 @@ __global__ __launch_bounds__(BK_THREADS, 6) void fwd_c1_kernel(PlanDev P, const 
                 Zs[tid * 3] = zs; Zs[tid * 3 + 1] = zl; Zs[tid * 3 + 2] = zu;
             }
             __syncthreads();   // Z visible (the DMA in flight is drained here too: acceptable for this light kernel)
-            if (Yout) {        // the shifted input (x, S_lo x, S_up x) per point, as scn_conv_dw_first takes it: Z verbatim
-                float* yb = Yout + ((size_t)slab * n_rows + m.row0) * (BK_NS * 3);
-                for (int i = tid; i < m.rows * 3; i += BK_THREADS) *(f32x4*)(yb + 4 * i) = *(const f32x4*)(Zs + 4 * i);
+            if (Yout) {        // the shifted input (x, S_lo x, S_up x, 0) per point, as the first-layer weight gradient takes it
+                float* yb = Yout + ((size_t)slab * n_rows + m.row0) * (BK_NS * Y_STRIDE);
+                for (int i = tid; i < m.rows * BK_NS; i += BK_THREADS)
+                    *(f32x4*)(yb + 4 * i) = f32x4{Zs[3 * i], Zs[3 * i + 1], Zs[3 * i + 2], 0.f};
             }
             float* o = out + ((size_t)slab * n_rows + m.row0) * (BK_NS * C);
             const int total = m.rows * BK_NS * CQ;
@@ -1668,7 +1671,27 @@ static_assert(B32_WFRAG_BYTES + 2048 <= 160 * 1024 - (2 * BK_SRC * 512 + BK_ELL_
 // PAIR: C = 16 on TWO slabs per visit -- the staged 512-byte piece is a point's 32 VIRTUAL channels (slab A's 16, slab B's 16:
 // the LDS-DMA's per-lane source address does the pairing), the weights are the block-diagonal diag(W, W), and aux / dx /
 // the weight-gradient blocks are addressed per slab; everything between is the C = 32 kernel as it stands.
-template <int ACT, bool EXT0 = false, bool PAIR = false>
+// y broadcast of the FIRST variant below: lane 32 h + 4 (R & 7) + g of yv0 (R < 8) / yv1 holds y[pt(R, h)][g]; a bit-mask
+// ds_swizzle with and = 0, or = j makes every lane read lane j of its own half (the pattern must be a literal: templates).
+template <int R>
+__device__ __forceinline__ void first_dw_step(float yv0, float yv1, float dx, float (&dwf)[3]) {
+    const int src = __float_as_int(R < 8 ? yv0 : yv1);
+    dwf[0] = fmaf(__int_as_float(__builtin_amdgcn_ds_swizzle(src, (4 * (R & 7) + 0) << 5)), dx, dwf[0]);
+    dwf[1] = fmaf(__int_as_float(__builtin_amdgcn_ds_swizzle(src, (4 * (R & 7) + 1) << 5)), dx, dwf[1]);
+    dwf[2] = fmaf(__int_as_float(__builtin_amdgcn_ds_swizzle(src, (4 * (R & 7) + 2) << 5)), dx, dwf[2]);
+}
+template <int... Rs>
+__device__ __forceinline__ void first_dw_tile(std::integer_sequence<int, Rs...>, float yv0, float yv1, const f32x16& dx,
+                                              float (&dwf)[3]) {
+    (first_dw_step<Rs>(yv0, yv1, dx[Rs], dwf), ...);
+}
+
+// FIRST: this layer's input is the FIRST layer's output (aux = H1 = act(y . W_first), y = the shifted 1-channel input saved by
+// scn_conv_forward_first).  The input gradient dx = dL/d(pre-activation of layer 1) is then needed for one thing only -- the
+// first layer's weight gradient dW_first[g][c] = sum_p y[p][g] dx[p][c] -- so it is contracted with y right here, in registers
+// (y is broadcast across the lanes of a half wave with ds_swizzle: 48 cross-lane reads + 48 FMAs per tile), and never written:
+// no 4*E*C-byte dx tensor, no separate streaming kernel over it.  DZ0 carries y in this variant.
+template <int ACT, bool EXT0 = false, bool PAIR = false, bool FIRST = false>
 __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, const float* __restrict__ DZ,
                                                                      const float* __restrict__ DZ0,
                                                                      const float* __restrict__ W0,
@@ -1676,9 +1699,11 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                                                      const float* __restrict__ W2,
                                                                      const float* __restrict__ aux,
                                                                      float* __restrict__ dx, float* __restrict__ partial,
-                                                                     int n_rows, int n_cols, int n_slabs, WorkList wl) {
+                                                                     int n_rows, int n_cols, int n_slabs, WorkList wl,
+                                                                     float* __restrict__ partial_first = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!(EXT0 && PAIR), "the power form exists for C = 32 only");
+    static_assert(!FIRST || (!EXT0 && !PAIR), "the fused first-layer gradient exists for the plain C = 32 form");
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
     constexpr int CH = PAIR ? 16 : 32;                       // channels of a stored point
     const SmemC32 sm = carve_c32(smem);
@@ -1721,6 +1746,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dWacc[g][r] = 0.f;
+    float dwf[3] = {0.f, 0.f, 0.f};                           // FIRST: this lane's share of dW_first[g][c = p]
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     SCN_UNIT_RANGE();
     uint32_t cqs[4];
@@ -1793,6 +1819,15 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                 const bool ok = 2 * (r >> 2) + h < rows_left && lane_live;
                 const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * CH : 0];
                 a[r] = ok ? v : 0.f;
+            }
+            // FIRST: the tile's y records, one float per lane and register, placed for a ds_swizzle broadcast inside each half wave:
+            // lane 32 h + 4 (r & 7) + g holds y[pt(r, h)][g], r < 8 in yv0 and r >= 8 (the points 16 higher) in yv1
+            float yv0 = 0.f, yv1 = 0.f;
+            if (FIRST) {
+                const int r7 = (lane >> 2) & 7, ypt = (r7 & 3) + 8 * (r7 >> 2) + 4 * h;
+                const float* yt = DZ0 + (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * Y_STRIDE + ypt * Y_STRIDE + (lane & 3);
+                if ((ypt >> 2) < rows_left) yv0 = yt[0];
+                if ((ypt >> 2) + 4 < rows_left) yv1 = yt[16 * Y_STRIDE];
             }
             constexpr int GSEQ[3] = {1, 2, 0};                           // segment order
             bf16x8 wn[3];
@@ -1874,6 +1909,8 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     STAMP_ADD(3);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(ACT, a[r]);   // dX = acc * act'(aux)
+                    if (FIRST)                                           // dW_first[g][c = p] += y[pt(r, h)][g] * dx[pt(r, h)][p]
+                        first_dw_tile(std::make_integer_sequence<int, 16>{}, yv0, yv1, acc, dwf);
                 }
                 // dW_g += aux^T T_g
 #pragma unroll
@@ -1889,7 +1926,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                  bl = __builtin_bit_cast(bf16x8, pl);
                     const Split3& at = At[t];
                     auto store = [&](int r) {                            // only in the last segment: acc is complete there
-                        if (u == 2 && dp && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
+                        if (!FIRST && u == 2 && dp && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
                     };
                     const int r0 = 8 * t;
                     dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bh, dWacc[g], 0, 0, 0);
@@ -1938,6 +1975,18 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
 #pragma unroll
         for (int w = 0; w < BK_WAVES; ++w) s += red[w * 3072 + i];
         outp[i] = s;
+    }
+    if (FIRST) {                                               // dW_first partial of this workgroup: [g][c], fixed order over (wave, h)
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 3; ++g) red[(wave * 2 + h) * 96 + g * 32 + p] = dwf[g];
+        __syncthreads();
+        if (threadIdx.x < 96) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 2 * BK_WAVES; ++w) s += red[w * 96 + threadIdx.x];
+            partial_first[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 96 + threadIdx.x] = s;
+        }
     }
 }
 
@@ -2225,8 +2274,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void gather3_c1_kernel(PlanDev P, co
                     zl = fmaf(e.v[2], d1, zl);
                     zu = fmaf(e.v[3], d1, zu);
                 }
-                float* y = Y + (((size_t)slab * n_rows + m.row0) * BK_NS + tid) * 3;
-                y[0] = zs; y[1] = zl; y[2] = zu;
+                *(f32x4*)(Y + (((size_t)slab * n_rows + m.row0) * BK_NS + tid) * Y_STRIDE) = f32x4{zs, zl, zu, 0.f};
             }
         }
     }
@@ -2251,8 +2299,8 @@ __global__ __launch_bounds__(DWS_THREADS) void dw_first_stream_kernel(const floa
         for (int u = 0; u < 4; ++u) {
             const int64_t j = i + u * stride;
             d[u] = *(const f32x4*)(DZ + j * 4);
-            const float* yp = Y + (j / CQ) * 3;
-            y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
+            const f32x4 yq = *(const f32x4*)(Y + (j / CQ) * Y_STRIDE);
+            y[u][0] = yq[0]; y[u][1] = yq[1]; y[u][2] = yq[2];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -2263,7 +2311,7 @@ __global__ __launch_bounds__(DWS_THREADS) void dw_first_stream_kernel(const floa
     }
     for (; i < total; i += stride) {
         const f32x4 d = *(const f32x4*)(DZ + i * 4);
-        const float* yp = Y + (i / CQ) * 3;
+        const float* yp = Y + (i / CQ) * Y_STRIDE;
         acc[0] += yp[0] * d;
         acc[1] += yp[1] * d;
         acc[2] += yp[2] * d;
@@ -2301,7 +2349,7 @@ __global__ __launch_bounds__(DWS_THREADS) void dw_first_list_kernel(PlanDev P, W
             const size_t p0 = ((size_t)wl.slab[k] * n_rows + row0) * BK_NS;   // first point
             for (int i = tid; i < count; i += DWS_THREADS) {     // i % CQ == tid % CQ: DWS_THREADS % CQ == 0
                 const f32x4 d = *(const f32x4*)(DZ + (p0 * CQ + i) * 4);
-                const float* yp = Y + (p0 + i / CQ) * 3;
+                const float* yp = Y + (p0 + i / CQ) * Y_STRIDE;
                 acc[0] += yp[0] * d;
                 acc[1] += yp[1] * d;
                 acc[2] += yp[2] * d;
@@ -2636,13 +2684,60 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
     return SCN_OK;
 }
 
+// Backward of the layer that follows the first one, fused with the first layer's weight gradient (bwd_c32_bf16_kernel<.., FIRST>).
+// Workspace: [this layer's dW partials][dW_first partials: 96 floats per workgroup].
+bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch) { return scone_shape(c) && ns == BK_NS && ch == 32; }
+
+size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch) {
+    if (!blocked_backward_first_supported(c, ns, ch)) return 0;
+    dim3 grid;
+    launch_grid(c, n_slabs, bwd_lds(32, 32), grid);
+    return (size_t)grid.x * grid.y * (3072 + 96) * sizeof(float);
+}
+
+int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
+                           const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
+                           hipStream_t st) {
+    PlanDev P = c->plan.dev;
+    const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
+    dim3 grid;
+    const size_t lds = bwd_lds(32, 32);
+    launch_grid(c, n_slabs, lds, grid);
+    P.assign = balanced_assignment(c, grid.x);
+    if (wl.block) grid.y = 1;
+    const int nr = c->n_rows, nc = c->g[0].n_cols;
+    const int n_wg = (int)(grid.x * grid.y);
+    float* partial = (float*)ws;
+    float* partial_first = partial + (size_t)n_wg * 3072;
+#define SCN_LAUNCH_BWDF(A)                                                                                        \
+    do {                                                                                                          \
+        SCN_ENSURE_LDS((bwd_c32_bf16_kernel<A, false, false, true>), lds);                                        \
+        hipLaunchKernelGGL((bwd_c32_bf16_kernel<A, false, false, true>), grid, dim3(BK_THREADS), lds, st, P, dz, y, W[0], \
+                           W[1], W[2], aux, (float*)nullptr, partial, nr, nc, n_slabs, wl, partial_first);        \
+    } while (0)
+    switch (act) {
+        case SCN_ACT_TANH: SCN_LAUNCH_BWDF(SCN_ACT_TANH); break;
+        case SCN_ACT_RELU: SCN_LAUNCH_BWDF(SCN_ACT_RELU); break;
+        case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWDF(SCN_ACT_LEAKY_RELU); break;
+        default: SCN_LAUNCH_BWDF(SCN_ACT_NONE); break;
+    }
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blocked_dw_reduce, dim3((32 * 3 * 32 + 255) / 256), dim3(256), 0, st, partial, n_wg, 32, 32, dW[0], dW[1],
+                       dW[2]);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(96), dim3(64), 0, st, partial_first, n_wg, 32, dW_first[0], dW_first[1],
+                       dW_first[2]);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
 // (with a y handed in the operator only supplies the row count and, for work lists, the block table)
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd) {
     return c->plan.built && c->n_groups == 1 && ns == BK_NS && (cd == 16 || cd == 32);
 }
 
 static size_t dw_first_y_bytes(const scn_conv_s* c, int n_slabs) {
-    const size_t b = (size_t)n_slabs * c->n_rows * BK_NS * 3 * sizeof(float);
+    const size_t b = (size_t)n_slabs * c->n_rows * BK_NS * Y_STRIDE * sizeof(float);
     return (b + 255) / 256 * 256;
 }
 

@@ -33,6 +33,11 @@ int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const flo
                           float* out, hipStream_t st);
 int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const float* g1, const float* const* W,
                            const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st);
+bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch);
+size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
+int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
+                           const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
+                           hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
@@ -455,6 +460,27 @@ int scn_conv_dw_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x,
     WorkList wlist{0, nullptr, nullptr, nullptr};
     if (wl) wlist = to_list(wl);
     return blocked_dw_first(c, n_slabs, x, y, dz, c_dz, dW, workspace, wl ? &wlist : nullptr, (hipStream_t)stream);
+}
+
+size_t scn_conv_backward_fused_first_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, int32_t channels) {
+    if (!c || n_slabs <= 0) return 0;
+    return blocked_backward_first_workspace(c, n_slabs, ns, channels);
+}
+
+int scn_conv_backward_fused_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* dz, const float* const* W,
+                                  const float* aux, int32_t channels, int32_t act, const float* y, float* const* dW,
+                                  float* const* dW_first, void* workspace, size_t workspace_bytes, const scn_work_list* wl,
+                                  void* stream) {
+    if (!c || !dz || !W || !W[0] || !W[1] || !W[2] || !aux || !y || !dW || !dW[0] || !dW[1] || !dW[2] || !dW_first ||
+        !dW_first[0] || !dW_first[1] || !dW_first[2] || !workspace || !valid_list(wl))
+        return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (n_slabs > 65535 || !blocked_backward_first_supported(c, ns, channels)) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < blocked_backward_first_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
+    WorkList wlist{0, nullptr, nullptr, nullptr};
+    if (wl) wlist = to_list(wl);
+    return blocked_backward_first(c, n_slabs, dz, W, aux, act, y, dW, dW_first, workspace, wl ? &wlist : nullptr,
+                                  (hipStream_t)stream);
 }
 
 int scn_conv_forward_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* x, const float* const* W, int32_t c_out,

@@ -4,6 +4,7 @@ ConvOp wraps a scn_conv_t; SconePlan / BunchPlan hold everything one model needs
 expose forward / backward over "flow slabs" ([n_slabs, rows, ns, C] fp32, see include/scone_hip.h).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -14,6 +15,7 @@ from .complex import Shift, union_pattern
 from .synthetic_data_gen import SparseFlows
 
 NS = 4   # trajectories per slab
+Y_STRIDE = 4   # floats per point of the shifted first-layer input y = (x, S_lo x, S_up x, 0)   (include/scone_hip.h)
 
 
 class KernelTimer:
@@ -70,6 +72,9 @@ class _timed:
 
 def _nbytes(*tensors):
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
+
+
+FUSE_FIRST = os.environ.get("SCN_NO_FUSED_FIRST") is None      # A/B switch: separate scn_conv_backward + scn_conv_dw_first
 
 
 def _stream():
@@ -209,7 +214,7 @@ class ConvOp:
         return dx if need_dx else None
 
     def forward_first(self, x, Ws, c_out, act, out=None, y=None, wl=None):
-        """First layer (one 1-channel input): returns (out, y) with y = (x, S_lo x, S_up x) per point, or None when the
+        """First layer (one 1-channel input): returns (out, y) with y = (x, S_lo x, S_up x, 0) per point, or None when the
         shape is not served (scn_conv_forward_first).  wl: as in forward (out and y given, all-zero)."""
         lib = _lib.load()
         S, rows, ns, c_in = x.shape
@@ -219,7 +224,7 @@ class ConvOp:
         if out is None:
             out = torch.empty((S, self.n_rows, ns, c_out), device=x.device, dtype=torch.float32)
         if y is None:
-            y = torch.empty((S, self.n_rows, ns, 3), device=x.device, dtype=torch.float32)
+            y = torch.empty((S, self.n_rows, ns, Y_STRIDE), device=x.device, dtype=torch.float32)
         with _timed("conv_fwd c1->%d" % c_out, None if wl is not None else _nbytes(x, out) + self.csr_bytes):
             st = lib.scn_conv_forward_first(self.handle, S, ns, _dev(x), ptr_array([_dev(w).value for w in Ws]), c_out,
                                             ACT[act], _dev(out), _dev(y), wl.ref() if wl is not None else None, _stream())
@@ -258,6 +263,26 @@ class ConvOp:
                                               ws.numel(), _stream()), "scn_conv_backward_power")
         return True, dx
 
+    def backward_fused_first(self, dz, Ws, aux, act, y, dWs, dWs_first, wl=None):
+        """Backward of the layer after the first one, fused with the first layer's weight gradient: dWs (this layer) and
+        dWs_first are accumulated, the input gradient is never written (scn_conv_backward_fused_first).  False when the shape
+        is not served."""
+        lib = _lib.load()
+        S, rows, ns, c = dz.shape
+        if tuple(aux.shape) != (S, rows, ns, c) or tuple(y.shape) != (S, rows, ns, Y_STRIDE) or self.n_groups != 1:
+            return False
+        nbytes = int(lib.scn_conv_backward_fused_first_workspace(self.handle, S, ns, c))
+        if nbytes == 0:
+            return False
+        ws = torch.empty(nbytes, device=dz.device, dtype=torch.uint8)
+        with _timed("conv_bwd c%d->%d + dW_first" % (c, c), None if wl is not None else _nbytes(dz, aux, y) + self.csr_bytes):
+            check(lib.scn_conv_backward_fused_first(self.handle, S, ns, _dev(dz), ptr_array([_dev(w).value for w in Ws]), _dev(aux),
+                                                    c, ACT[act], _dev(y), ptr_array([_dev(d).value for d in dWs]),
+                                                    ptr_array([_dev(d).value for d in dWs_first]),
+                                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                                    wl.ref() if wl is not None else None, _stream()), "scn_conv_backward_fused_first")
+        return True
+
     def clear(self, t, wl):
         """Zero the listed items of a [S, rows, ns, C] tensor (scn_clear_list)."""
         check(_lib.load().scn_clear_list(self.handle, t.shape[2], t.shape[3], _dev(t), wl.ref(), _stream()), "scn_clear_list")
@@ -274,7 +299,7 @@ class ConvOp:
         forward_first (or None: recomputed from x).  False if the shape is not served."""
         lib = _lib.load()
         S, rows, ns, c = dz.shape
-        assert rows == self.n_rows and (y is None or tuple(y.shape) == (S, rows, ns, 3))
+        assert rows == self.n_rows and (y is None or tuple(y.shape) == (S, rows, ns, Y_STRIDE))
         nbytes = int(lib.scn_conv_dw_first_workspace(self.handle, S, ns, c))
         if nbytes == 0:
             return False
@@ -483,7 +508,7 @@ class SconePlan:
             first = None
             if i == 0:
                 first = self.conv.forward_first(x, w, c_out, self.act, out=out,
-                                                y=self._zeros((S, E, ns, 3)) if activity else None, wl=wl)
+                                                y=self._zeros((S, E, ns, Y_STRIDE)) if activity else None, wl=wl)
                 assert first is not None or not activity
             if first is not None:                       # 1-channel input: keep the shifted input for the weight gradient
                 hs.append(first[0])
@@ -662,11 +687,18 @@ class SconePlan:
         S, E, ns, C = hs[-1].shape
         L = len(hs) - 1
         dz = dz_top
+        fused_first = False
         for i in reversed(range(L)):
+            if i == 0 and fused_first:
+                break                                   # the first layer's weight gradient came out of layer 1's backward
             wl_out = activity["bwd"][i] if (activity and i > 0) else None      # items of this layer's input gradient
             wl_in = activity["bwd"][i + 1] if activity else None                # support of dz
             dz_in = dz
-            if i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3], wl=wl_in):
+            if i == 1 and hs[0].shape[3] == 1 and y0 is not None and FUSE_FIRST and \
+                    self.conv_T.backward_fused_first(dz, weights[3:6], hs[1], self.act, y0, grads[3:6], grads[0:3], wl=wl_out):
+                fused_first = True                      # dx of this layer only feeds dW_first: contracted in registers, never written
+                dz = None
+            elif i == 0 and hs[0].shape[3] == 1 and self.conv.dw_first(hs[0], y0, dz, grads[0:3], wl=wl_in):
                 dz = None                               # first layer: shifted 1-channel input x one stream over dz
             else:
                 assert not activity or i > 0, "zero-skipping needs the first-layer fast path"
@@ -722,7 +754,7 @@ class PowerPlan(SconePlan):
                 g2 = self._shift(self.op, g1)
                 out = dense_terms_forward([hs[-1], g1, g2], w, w[0].shape[1], self.act)
                 if i == 0 and x.shape[3] == 1:
-                    y0 = torch.cat([x, g1, g2], dim=3)  # the shifted input per point, for the first layer's weight gradient
+                    y0 = torch.cat([x, g1, g2, torch.zeros_like(x)], dim=3)  # the shifted input per point, for the first layer's weight gradient
             hs.append(out)
         return hs, y0
 

@@ -411,7 +411,8 @@ def test_first_layer_fast_path_matches_generic_entry_points(cfg1, sc1, hidden):
     xs = x.cpu().numpy().astype(np.float64)[..., 0]                    # (S, E, 4)
     for s in range(S):
         ref = np.stack([xs[s], lo @ xs[s], up @ xs[s]], axis=-1)       # (E, 4, 3)
-        assert _maxdiff(y[s].cpu().numpy(), ref) <= 2e-5
+        assert _maxdiff(y[s].cpu().numpy()[..., :3], ref) <= 2e-5
+        assert float(y[s][..., 3].abs().max()) == 0.0                  # 16-byte records (x, S_lo x, S_up x, 0)
     g_ref = [torch.zeros_like(w) for w in W]
     plan.conv_T.backward([dz], W, x, "tanh", False, g_ref)
     for yy in (None, y):
@@ -662,3 +663,44 @@ def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
     assert abs(loss - ref[2]) <= 1e-5 and acc == ref[3]
     t2 = net.two_target_accuracy(shifts, inputs, y, test_mask, n_nbrs)
     assert 0.0 <= t2 <= 1.0
+
+
+@pytest.mark.parametrize("mode", ["dense", "zeros"])
+def test_fused_first_layer_gradient_equals_the_separate_kernels(mode):
+    """scn_conv_backward_fused_first (layer 1's backward contracts its input gradient with the shifted input y in registers and
+    never writes it) against scn_conv_backward + scn_conv_dw_first on the same step: loss and all ten weight gradients."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(6000)
+    sc = SimplicialComplex(cx)
+    N = 22
+    paths = g.generate_random_walks(cx, m=N, seed=4, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=5)
+    y = so.onehot_targets(choice, sc.max_degree)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    res = {}
+    keep = ops.FUSE_FIRST
+    try:
+        for fused in (True, False):
+            ops.FUSE_FIRST = fused
+            stm.reseed(1030)
+            net = stm.Scone_GCN(1, 1e-3, N, 0.0, verbose=False, skip_mode=mode)
+            net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+            with torch.no_grad():
+                for w in net.weights:
+                    w.mul_(15.0)
+            with ops.KernelTimer() as kt:
+                loss = float(net.grad_step_staged(inputs, net.stage(inputs, y, np.arange(N)), N, apply=False))
+            assert any("dW_first" in k for k in kt.summary()) == fused          # the fused entry point really ran
+            res[fused] = (loss, [t.detach().cpu().numpy().astype(np.float64) for t in net._grads])
+    finally:
+        ops.FUSE_FIRST = keep
+    assert abs(res[True][0] - res[False][0]) <= 1e-7 * max(1.0, abs(res[False][0]))
+    gmax = max(np.abs(b).max() for b in res[False][1])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert np.abs(a - b).max() <= 2e-6 * gmax
