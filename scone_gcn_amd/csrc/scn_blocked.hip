@@ -1011,35 +1011,56 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
         const int tw = tws[wave];                    // width of this wave's own 4 rows
         const int twu = EXT0 ? 0 : P.tile_wu4[b * W16_WAVES + wave];
         const int rtc = rt < m.rows ? rt : m.rows - 1;
-        uint32_t goff[NDMA];
+        // LDS-DMA instruction k of this wave moves chunks c = (k * 16 + wave) * 64 + lane: slot = 2 * (k * 16 + wave) + (lane >> 5),
+        // position lane & 31; the swizzled source chunk depends on slot & 3 = ((wave & 1) << 1) | (lane >> 5) only: ONE lane
+        // constant for every k, the slot's source row comes from LDS at a lane constant + 128 * k bytes
         const int total = m.nsrc * CPP;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int c = (i * W16_WAVES + wave) * 64 + lane;
-            const int slot = c / CPP, pos = c % CPP;
-            goff[i] = c < total ? (uint32_t)sm.srcrows[slot] * PIECE + swz32(slot, pos) * 16 : 0u;
-        }
+        const uint32_t dchunk = (uint32_t)swz32(((wave & 1) << 1) | (lane >> 5), lane & 31) * 16;
+        const int32_t* my_src = sm.srcrows + 2 * wave + (lane >> 5);          // + 32 * k
         auto dma = [&](int k, const char* Xs, char* buf) {
             const int base = (k * W16_WAVES + wave) * 64;
             if (base + lane < total)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xs + goff[k]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xs + ((uint32_t)my_src[32 * k] * PIECE + dchunk)),
                                                  (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
         };
+        auto slab_base = [&](int slab) {               // wave-uniform: SGPR base + 32-bit lane offset in the LDS-DMA
+            const uint64_t v = (uint64_t)((const char*)X + (size_t)slab * slab_bytes);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return (const char*)(((uint64_t)hi << 32) | lo);
+        };
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) dma(i, (const char*)X + (size_t)SLAB_AT(0) * slab_bytes, sm.buf(0));
-        for (int it = 0; it < n_it; ++it) {
+        for (int i = 0; i < NDMA; ++i) dma(i, slab_base(SLAB_AT(0)), sm.buf(0));
+#ifndef SCN_FWD_NO_STAGGER
+        // STAGGER.  A slab visit has two phases per wave: GATHER (LDS reads + FMAs -- with all sixteen waves in it at once the
+        // LDS pipe is the limit) and CONTRACT (split + MFMA + activation: matrix pipe and VALU).  Waves 8-15 run half a visit
+        // behind waves 0-7 (every SIMD hosts two of each): while one half gathers slab v the other contracts slab v - 1.  The
+        // loop walks HALF-STEPS hs; a wave gathers at hs = 2v + late and contracts at hs = 2v + 1 + late; the slab barrier stays
+        // at the even half-steps.  A late wave carries its gathered z across the barrier; its share of the next LDS-DMA is one
+        // visit further ahead (slab v + 2), the early waves' as before (slab v + 1).
+        const int late = wave >> 3;
+        if (late && n_it > 1) {                        // the late waves' share of slab 1 has no contraction to ride in
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) dma(i, slab_base(SLAB_AT(1)), sm.buf(1));
+        }
+#else
+        const int late = 0;
+#endif
+        f32x4 z[3][2];                                 // [segment][chunk q]: channels 8*kq + 4*q .. +3 of this lane's point
+        for (int hs = 0; hs <= 2 * n_it; ++hs) {
+            if ((hs & 1) == 0) {
+                STAMP_START();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP_ADD(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                STAMP_ADD(1);
+            }
+            const int hv = hs - late;
+            if (hv < 0 || hv >= 2 * n_it) continue;
+            const int it = hv >> 1;
             const int slab = SLAB_AT(it);
-            STAMP_START();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP_ADD(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            STAMP_ADD(1);
-            const bool more = it + 1 < n_it;
-            const char* Xn = (const char*)X + (size_t)(more ? SLAB_AT(it + 1) : slab) * slab_bytes;
-            char* nbuf = sm.buf((it + 1) & 1);
-            f32x4 z[3][2];                 // [segment][chunk q]: channels 8*kq + 4*q .. +3 of this lane's point
-            {
+            if ((hv & 1) == 0) {
+                // ---------------- GATHER
                 const uint32_t cb[2] = {cqs[0] | (uint32_t)((it & 1) << 16), cqs[1] | (uint32_t)((it & 1) << 16)};
                 if (EXT0) {
                     const float* x0 = X0 + (((size_t)slab * n_rows + m.row0 + rtc) * BK_NS + n) * 32 + 8 * kq;
@@ -1050,10 +1071,15 @@ __global__ __launch_bounds__(W16_THREADS, 4) void fwd_c32_w16_kernel(PlanDev P, 
                 } else {
                     gather_c32<2>(sm, rtc, m.w, tw, twu, cb, z[0], z[1], z[2]);
                 }
+                STAMP_ADD(2);
+                continue;
             }
-            STAMP_ADD(2);
-            // MFMA: out^T tile (16 channels x 16 points) x 2 channel tiles; LDS-DMA of the next slab and the previous tile's
-            // two 16-byte stores ride inside the chains
+            // ---------------- CONTRACT: out^T tile (16 channels x 16 points) x 2 channel tiles; the LDS-DMA of the next slab and
+            // the previous tile's two 16-byte stores ride inside the chains
+            const int vdma = it + 1 + late;
+            const bool more = vdma < n_it;
+            const char* Xn = slab_base(more ? SLAB_AT(vdma) : slab);
+            char* nbuf = sm.buf(vdma & 1);
             {
                 const f32x4 prev0 = pend[0], prev1 = pend[1];
                 float* const prev_ptr = pend_ptr;
