@@ -257,6 +257,24 @@ int scn_conv_backward_fused_first(scn_conv_t conv_t, int32_t n_slabs, int32_t ns
                                   float* const* dW_first, void* workspace, size_t workspace_bytes,
                                   const scn_work_list* wl /* NULL: dense */, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Fused Bunch (SCCONV) layer, TE:173-195: the seven shifts S_ab as ONE square operator on the concatenated row space
+ * [nodes | edges | faces] (an index space only: the three level tensors stay separate allocations).  Entry (r, c) carries
+ * TERM = the level of column c; row r has CLASS = its own level; level_row0[l] = first concatenated index of level l
+ * (level_row0[0] = 0, level_row0[3] = n_rows).  Weights are addressed [class][term] (9 pointers, NULL = the class has no such
+ * term: nodes have no face term, faces no node term).
+ *   scn_terms_forward :  out_l = act( sum_j (S_{j->l} x_j) W[l][j] )   -- one launch for the three levels of a layer
+ *       x[j]   device [n_slabs][rows_j][ns][32] or NULL (level identically zero)
+ *       out[l] device [n_slabs][rows_l][ns][32] or NULL (level not wanted: skipped)
+ * Served for ns = 4, 32 -> 32 channels (SCN_ERR_UNSUPPORTED otherwise: use the per-shift scn_spmm_dual + scn_dense_terms_*).
+ * The handle is a scn_conv_t (scn_conv_destroy frees it).
+ * --------------------------------------------------------------------------------------------------- */
+int scn_terms_create(int32_t n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const uint8_t* term,
+                     const int32_t* level_row0 /* [4] */, scn_conv_t* out);
+int scn_terms_forward(scn_conv_t op, int32_t n_slabs, int32_t ns, const float* const* x /* [3] */,
+                      const float* const* W /* [9] = [class][term], each [32][32] */, int32_t channels, int32_t act,
+                      float* const* out /* [3] */, void* stream);
+
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)
  * returns order[new] = old that sorts the rows of every block the plan would cut by descending entry count, so the

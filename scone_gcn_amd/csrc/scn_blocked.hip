@@ -2923,6 +2923,8 @@ int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, f
     return SCN_OK;
 }
 
+#include "scn_terms.inc"
+
 }  // namespace scn
 
 

@@ -38,6 +38,9 @@ size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns
 int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
                            const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
                            hipStream_t st);
+int build_terms_plan(scn_conv_s* c, const uint8_t* term, const int32_t* lvl_row0);
+int terms_forward(scn_conv_s* c, int n_slabs, const float* const* x, const float* const* W, int act, float* const* out,
+                  hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
@@ -371,12 +374,58 @@ int scn_conv_create_blocked(int32_t n_rows, int32_t n_groups, const scn_group_de
     return SCN_OK;
 }
 
+int scn_terms_create(int32_t n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const uint8_t* term,
+                     const int32_t* level_row0, scn_conv_t* out) {
+    if (!out || !rowptr || !level_row0 || n_rows <= 0) return SCN_ERR_BAD_ARG;
+    *out = nullptr;
+    const int64_t nnz = rowptr[n_rows];
+    if (rowptr[0] != 0 || nnz < 0 || (nnz > 0 && (!col || !val || !term))) return SCN_ERR_BAD_ARG;
+    if (level_row0[0] != 0 || level_row0[1] < 0 || level_row0[2] < level_row0[1] || level_row0[3] != n_rows ||
+        level_row0[2] > n_rows)
+        return SCN_ERR_BAD_SHAPE;
+    for (int r = 0; r < n_rows; ++r)
+        if (rowptr[r + 1] < rowptr[r]) return SCN_ERR_BAD_SHAPE;
+    for (int64_t j = 0; j < nnz; ++j) {
+        if (col[j] < 0 || col[j] >= n_rows || term[j] > 2) return SCN_ERR_BAD_SHAPE;
+        if (term[j] != (col[j] >= level_row0[1]) + (col[j] >= level_row0[2])) return SCN_ERR_BAD_SHAPE;   // term = level of the column
+    }
+    scn_conv_s* c = new (std::nothrow) scn_conv_s();
+    if (!c) return SCN_ERR_NOMEM;
+    c->n_rows = n_rows;
+    c->n_groups = 1;
+    Group& G = c->g[0];
+    G.n_cols = n_rows; G.identity = 0; G.n_vals = 1; G.nnz = nnz; G.slot_base = 0; G.n_slots = 1;
+    c->n_slots = 1;
+    c->slot_group[0] = 0; c->slot_kind[0] = 1;
+    try {
+        G.h_rowptr.assign(rowptr, rowptr + n_rows + 1);
+        G.h_col.assign(col, col + nnz);
+        G.h_val0.assign(val, val + nnz);
+    } catch (...) { delete c; return SCN_ERR_NOMEM; }
+    const int st = build_terms_plan(c, term, level_row0);
+    if (st != SCN_OK) { scn_conv_destroy(c); return st; }
+    *out = c;
+    return SCN_OK;
+}
+
+int scn_terms_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* x, const float* const* W, int32_t channels,
+                      int32_t act, float* const* out, void* stream) {
+    if (!c || !x || !W || !out) return SCN_ERR_BAD_ARG;
+    if (!c->terms.built) return SCN_ERR_UNSUPPORTED;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (ns != BK_NS || channels != 32 || n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
+    for (int l = 0; l < 3; ++l)
+        if (out[l] && c->terms.lvl_row0[l + 1] == c->terms.lvl_row0[l]) return SCN_ERR_BAD_SHAPE;
+    return terms_forward(c, n_slabs, x, W, act, out, (hipStream_t)stream);
+}
+
 int scn_conv_n_slots(scn_conv_t c) { return c ? c->n_slots : SCN_ERR_BAD_ARG; }
 
 int scn_conv_plan_info(scn_conv_t c, int32_t* n_blocks, float* mean_sources_per_row) {
     if (!c) return SCN_ERR_BAD_ARG;
-    if (n_blocks) *n_blocks = c->plan.built ? c->plan.dev.n_blocks : 0;
-    if (mean_sources_per_row) *mean_sources_per_row = c->plan.built ? (float)c->plan.mean_src_per_row : 0.f;
+    const bool has = c->plan.built || c->terms.built;
+    if (n_blocks) *n_blocks = has ? c->plan.dev.n_blocks : 0;
+    if (mean_sources_per_row) *mean_sources_per_row = has ? (float)c->plan.mean_src_per_row : 0.f;
     return SCN_OK;
 }
 

@@ -115,6 +115,16 @@ struct WorkList {
     const int32_t* slab;    // active slabs of each listed block, ascending
 };
 
+// extra plan arrays of a "terms" operator (fused Bunch layer, scn_terms.inc); the common part lives in BlockPlan
+struct TermsPlan {
+    bool built = false;
+    const uint8_t* blk_class = nullptr;
+    const uint8_t* grp4 = nullptr;
+    const uint8_t* grp8 = nullptr;
+    int32_t lvl_row0[4] = {0, 0, 0, 0};
+    std::vector<uint8_t> h_class;
+};
+
 struct BlockPlan {
     bool built = false;
     PlanDev dev{};
@@ -133,5 +143,6 @@ struct scn_conv_s {
     int32_t slot_group[SCN_MAX_SLOTS] = {0, 0, 0, 0};
     int32_t slot_kind[SCN_MAX_SLOTS] = {0, 0, 0, 0};   // 0 identity, 1 val0, 2 val1
     scn::BlockPlan plan;
+    scn::TermsPlan terms;
     std::vector<uint8_t> block_start;   // optional layout hint: 1 where a block of the plan must start (see scn_plan_refine_order)
 };

@@ -75,6 +75,7 @@ def _nbytes(*tensors):
 
 
 FUSE_FIRST = os.environ.get("SCN_NO_FUSED_FIRST") is None      # A/B switch: separate scn_conv_backward + scn_conv_dw_first
+FUSE_BUNCH = os.environ.get("SCN_NO_FUSED_BUNCH") is None      # A/B switch: per-shift SpMMs + dense-term kernels for every Bunch layer
 
 
 def _stream():
@@ -321,6 +322,66 @@ class ConvOp:
             check(lib.scn_spmm_dual(self.handle, S, k, _dev(x), _dev(ya), _dev(yb) if dual else None, _stream()),
                   "scn_spmm_dual")
         return ya, yb
+
+
+class TermsOp:
+    """The seven Bunch shifts of one direction as ONE operator on the concatenated row space [nodes | edges | faces]
+    (scn_terms_create): blocks[(l, j)] = the shift (device order) from source level j to target level l, or absent."""
+
+    def __init__(self, sizes, blocks):
+        import scipy.sparse as sp
+        lib = _lib.load()
+        self.sizes = tuple(int(x) for x in sizes)
+        off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        grid = [[blocks.get((l, j)) for j in range(3)] for l in range(3)]
+        for l in range(3):
+            for j in range(3):
+                if grid[l][j] is None:
+                    grid[l][j] = sp.csr_matrix((self.sizes[l], self.sizes[j]))
+        M = sp.bmat(grid, format="csr")
+        M.sort_indices()
+        R = int(off[3])
+        rowptr = np.ascontiguousarray(M.indptr, np.int32)
+        col = np.ascontiguousarray(M.indices, np.int32)
+        val = np.ascontiguousarray(M.data, np.float32)
+        term = ((col >= off[1]).astype(np.uint8) + (col >= off[2]).astype(np.uint8)).astype(np.uint8)
+        lvl = np.ascontiguousarray(off, np.int32)
+        h = ctypes.c_void_p()
+        check(lib.scn_terms_create(R, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, term.ctypes.data, lvl.ctypes.data,
+                                   ctypes.byref(h)), "scn_terms_create")
+        self.handle = h
+        self.nnz = int(M.nnz)
+        self.csr_bytes = 4.0 * self.nnz * 2 + 4.0 * (R + 1)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().scn_conv_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def plan_info(self):
+        nb, ms = ctypes.c_int32(0), ctypes.c_float(0)
+        check(_lib.load().scn_conv_plan_info(self.handle, ctypes.byref(nb), ctypes.byref(ms)), "scn_conv_plan_info")
+        return nb.value, ms.value
+
+    def forward(self, xs, Ws, act, want):
+        """xs[j]: level tensors [S, rows_j, ns, 32] or None (identically zero); Ws[l][j]: (32, 32) tensors or None; want[l]:
+        compute level l.  Returns the list of outputs (None where not wanted)."""
+        lib = _lib.load()
+        ref = next(x for x in xs if x is not None)
+        S, ns = ref.shape[0], ref.shape[2]
+        outs = [torch.empty((S, self.sizes[l], ns, 32), device=ref.device, dtype=torch.float32) if want[l] else None
+                for l in range(3)]
+        flatW = [Ws[l][j] for l in range(3) for j in range(3)]
+        nb = _nbytes(*[x for x in xs if x is not None], *[o for o in outs if o is not None]) + self.csr_bytes
+        with _timed("terms_fwd c32", nb):
+            check(lib.scn_terms_forward(self.handle, S, ns, ptr_array([_dev(x).value if x is not None else None for x in xs]),
+                                        ptr_array([_dev(w).value if w is not None else None for w in flatW]), 32, ACT[act],
+                                        ptr_array([_dev(o).value if o is not None else None for o in outs]), _stream()),
+                  "scn_terms_forward")
+        return outs
 
 
 def _pairable(widths, ns):
@@ -830,6 +891,7 @@ class BunchPlan:
         self.bwd_slots = [[k for k in range(7) if BUNCH_SRC[k] == lvl] for lvl in range(3)]
         self._dev_csr = dev
         self._generic = None
+        self._terms = None                              # fused-layer operators (forward, transposed), built on first use
         nb = np.asarray(nbrhoods)
         pn = self.layout.perm[0]
         # padding index -1 wraps to the LAST node of the caller's numbering (TE:201); resolve it here, in device order
@@ -847,6 +909,18 @@ class BunchPlan:
                    for lvl in range(3)]
             self._generic = (fwd, bwd)
         return self._generic
+
+    def _terms_ops(self):
+        """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer."""
+        if self._terms is None:
+            dev = self._dev_csr
+            fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)})
+            self._terms = (fwd, None)
+        return self._terms
+
+    @staticmethod
+    def _slot(dst, src):
+        return next((k for k in range(7) if BUNCH_DST[k] == dst and BUNCH_SRC[k] == src), None)
 
     @staticmethod
     def _blocked_ok(ns, c):
@@ -876,6 +950,20 @@ class BunchPlan:
         states, zeros = [cur], [zero]
         for i in range(L):
             nxt, nzero = [], []
+            c_outs = {weights[7 * i + k].shape[1] for k in range(7)}
+            c_ins = {cur[l].shape[3] for l in range(3) if not zero[l] and cur[l] is not None}
+            if FUSE_BUNCH and ns == NS and c_outs == {32} and c_ins == {32}:
+                # fused layer: one launch for the three levels (scn_terms_forward)
+                xs = [None if (zero[l] or cur[l] is None) else cur[l] for l in range(3)]
+                Ws = [[None] * 3 for _ in range(3)]
+                for k in range(7):
+                    if xs[BUNCH_SRC[k]] is not None:
+                        Ws[BUNCH_DST[k]][BUNCH_SRC[k]] = weights[7 * i + k]
+                outs = self._terms_ops()[0].forward(xs, Ws, "relu", need[i + 1])
+                cur, zero = outs, [o is None for o in outs]
+                states.append(cur)
+                zeros.append(zero)
+                continue
             for lvl in range(3):
                 if not need[i + 1][lvl]:
                     nxt.append(None)
