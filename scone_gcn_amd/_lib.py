@@ -92,7 +92,8 @@ SIGNATURES = {
     "scn_conv_backward_fused_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_i32,
                                                      c_i32, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p,
                                                      c_size_t, ctypes.POINTER(WorkListDesc), c_void_p]),
-    "scn_terms_create": (ctypes.c_int, [c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
+    "scn_terms_create": (ctypes.c_int, [c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                                        ctypes.POINTER(c_void_p)]),
     "scn_terms_forward": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_i32, c_i32,
                                          ctypes.POINTER(c_void_p), c_void_p]),
     "scn_masked_ce": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_f32, c_void_p, c_void_p, c_void_p]),

@@ -72,8 +72,9 @@ class Layout:
     """Row permutation of the three levels: perm[level][old] = new, order[level][new] = old; block_starts[level] is the
     optional cut hint for the LDS-blocked plan (1 where a block begins) that goes with the order."""
 
-    def __init__(self, sizes, orders=None, block_starts=None):
+    def __init__(self, sizes, orders=None, block_starts=None, merged=None):
         self.sizes = tuple(int(s) for s in sizes)
+        self.merged = merged            # optional uint8 [sum(sizes)]: level of the i-th simplex along ONE curve through all levels
         self.order = []
         self.perm = []
         self.block_starts = list(block_starts) if block_starts is not None else [None, None, None]
@@ -424,10 +425,38 @@ class SimplicialComplex:
         L1 = (L_lo + L_up).tocsr()
         return [Shift(L1, self.layout, 1, 1), Shift((L1 @ L1).tocsr(), self.layout, 1, 1)]   # TE:251-253
 
+    def bunch_layout(self):
+        """Row orders for the Bunch model: every level along the SAME Hilbert curve (keys of the simplex centroids in one
+        common frame, no per-block re-sorting), plus the merged order of the three levels along that curve -- the fused Bunch
+        layer cuts its blocks as patches across the levels (scn_terms_create).  Without coordinates: the default orders, merged
+        level by level (correct, but the patches then have no cross-level locality)."""
+        if getattr(self, "_bunch_layout", None) is None:
+            cx = self.cx
+            sizes = (cx.n_nodes, cx.n_edges, cx.n_faces)
+            if cx.coords is not None and cx.n_edges > 1 and cx.n_faces > 0:
+                c = np.asarray(cx.coords, np.float64)
+                pts = [c[:cx.n_nodes], 0.5 * (c[cx.edges[:, 0]] + c[cx.edges[:, 1]]), c[cx.faces].mean(axis=1)]
+                lo, hi = c.min(axis=0), c.max(axis=0)
+                orders, keys = [], []
+                for p in pts:
+                    q = ((p - lo) / np.maximum(hi - lo, 1e-30) * 65535.0).astype(np.int64)
+                    k = hilbert_index(q[:, 0], q[:, 1])
+                    o = np.argsort(k, kind="stable")
+                    orders.append(o)
+                    keys.append(k[o])
+                lvl = np.concatenate([np.full(n, l, np.uint8) for l, n in enumerate(sizes)])
+                merged = lvl[np.argsort(np.concatenate(keys), kind="stable")]
+                self._bunch_layout = Layout(sizes, orders, None, merged=np.ascontiguousarray(merged, np.uint8))
+            else:
+                merged = np.concatenate([np.full(n, l, np.uint8) for l, n in enumerate(sizes)])
+                self._bunch_layout = Layout(sizes, [self.layout.order[l] for l in range(3)], None, merged=merged)
+        return self._bunch_layout
+
     def bunch_shifts(self):
         S = compute_shift_matrices(self.B1, self.B2)                                           # TE:255-257
         lv = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2)]   # (row level, col level) of S_00,S_10,S_01,S_11,S_21,S_12,S_22
-        return [Shift(m, self.layout, r, c) for m, (r, c) in zip(S, lv)]
+        lay = self.bunch_layout()
+        return [Shift(m, lay, r, c) for m, (r, c) in zip(S, lv)]
 
     def bconds(self, flips=None):
         return Bconds(self.cx, self.layout, self.nbrhoods, flips)

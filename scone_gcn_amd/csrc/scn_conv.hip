@@ -38,7 +38,8 @@ size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns
 int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
                            const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
                            hipStream_t st);
-int build_terms_plan(scn_conv_s* c, const uint8_t* term, const int32_t* lvl_row0);
+int build_terms_plan(scn_conv_s* c, const uint8_t* term, const int32_t* lvl_row0, const uint8_t* merged, const int32_t* bins,
+                     int group_rows);
 int terms_forward(scn_conv_s* c, int n_slabs, const float* const* x, const float* const* W, int act, float* const* out,
                   hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
@@ -375,8 +376,19 @@ int scn_conv_create_blocked(int32_t n_rows, int32_t n_groups, const scn_group_de
 }
 
 int scn_terms_create(int32_t n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const uint8_t* term,
-                     const int32_t* level_row0, scn_conv_t* out) {
-    if (!out || !rowptr || !level_row0 || n_rows <= 0) return SCN_ERR_BAD_ARG;
+                     const int32_t* level_row0, const uint8_t* merged, const int32_t* bins, int32_t rows_per_wave,
+                     scn_conv_t* out) {
+    if (!out || !rowptr || !level_row0 || !merged || !bins || n_rows <= 0) return SCN_ERR_BAD_ARG;
+    if (rows_per_wave != 4 && rows_per_wave != 8) return SCN_ERR_BAD_ARG;
+    {
+        int64_t seen[3] = {0, 0, 0};
+        for (int i = 0; i < n_rows; ++i) {
+            if (merged[i] > 2) return SCN_ERR_BAD_SHAPE;
+            ++seen[merged[i]];
+        }
+        for (int l = 0; l < 3; ++l)
+            if (seen[l] != level_row0[l + 1] - level_row0[l]) return SCN_ERR_BAD_SHAPE;   // every row exactly once
+    }
     *out = nullptr;
     const int64_t nnz = rowptr[n_rows];
     if (rowptr[0] != 0 || nnz < 0 || (nnz > 0 && (!col || !val || !term))) return SCN_ERR_BAD_ARG;
@@ -402,7 +414,7 @@ int scn_terms_create(int32_t n_rows, const int32_t* rowptr, const int32_t* col, 
         G.h_col.assign(col, col + nnz);
         G.h_val0.assign(val, val + nnz);
     } catch (...) { delete c; return SCN_ERR_NOMEM; }
-    const int st = build_terms_plan(c, term, level_row0);
+    const int st = build_terms_plan(c, term, level_row0, merged, bins, rows_per_wave);
     if (st != SCN_OK) { scn_conv_destroy(c); return st; }
     *out = c;
     return SCN_OK;

@@ -118,11 +118,13 @@ struct WorkList {
 // extra plan arrays of a "terms" operator (fused Bunch layer, scn_terms.inc); the common part lives in BlockPlan
 struct TermsPlan {
     bool built = false;
-    const uint8_t* blk_class = nullptr;
-    const uint8_t* grp4 = nullptr;
-    const uint8_t* grp8 = nullptr;
+    int group_rows = 0;                 // rows per wave of the kernel the plan was cut for (4: forward, 8: backward)
+    int32_t bins[3] = {0, 0, 0};        // rows of each level a block can hold
+    const int32_t* blk_row0 = nullptr;  // [n_blocks][3]
+    const uint8_t* blk_rows = nullptr;  // [n_blocks][4]
+    const uint8_t* blk_w = nullptr;     // [n_blocks][4]
+    const uint8_t* grp = nullptr;       // [n_blocks][16][5]
     int32_t lvl_row0[4] = {0, 0, 0, 0};
-    std::vector<uint8_t> h_class;
 };
 
 struct BlockPlan {

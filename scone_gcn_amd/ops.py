@@ -328,10 +328,11 @@ class TermsOp:
     """The seven Bunch shifts of one direction as ONE operator on the concatenated row space [nodes | edges | faces]
     (scn_terms_create): blocks[(l, j)] = the shift (device order) from source level j to target level l, or absent."""
 
-    def __init__(self, sizes, blocks):
+    def __init__(self, sizes, blocks, merged, bins, rows_per_wave):
         import scipy.sparse as sp
         lib = _lib.load()
         self.sizes = tuple(int(x) for x in sizes)
+        self.bins = tuple(int(b) for b in bins)
         off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
         grid = [[blocks.get((l, j)) for j in range(3)] for l in range(3)]
         for l in range(3):
@@ -346,9 +347,14 @@ class TermsOp:
         val = np.ascontiguousarray(M.data, np.float32)
         term = ((col >= off[1]).astype(np.uint8) + (col >= off[2]).astype(np.uint8)).astype(np.uint8)
         lvl = np.ascontiguousarray(off, np.int32)
+        if merged is None:                                     # no common curve known: level by level
+            merged = np.concatenate([np.full(n, l, np.uint8) for l, n in enumerate(self.sizes)])
+        merged = np.ascontiguousarray(merged, np.uint8)
+        assert len(merged) == R
+        binsa = np.ascontiguousarray(self.bins, np.int32)
         h = ctypes.c_void_p()
         check(lib.scn_terms_create(R, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, term.ctypes.data, lvl.ctypes.data,
-                                   ctypes.byref(h)), "scn_terms_create")
+                                   merged.ctypes.data, binsa.ctypes.data, int(rows_per_wave), ctypes.byref(h)), "scn_terms_create")
         self.handle = h
         self.nnz = int(M.nnz)
         self.csr_bytes = 4.0 * self.nnz * 2 + 4.0 * (R + 1)
@@ -914,7 +920,8 @@ class BunchPlan:
         """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer."""
         if self._terms is None:
             dev = self._dev_csr
-            fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)})
+            # bins: rows of (nodes, edges, faces) a block holds = the natural 0.37 : 1 : 0.67 proportions in wave units
+            fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)}, self.layout.merged, (12, 32, 20), 4)
             self._terms = (fwd, None)
         return self._terms
 
