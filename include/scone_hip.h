@@ -279,6 +279,20 @@ int scn_terms_forward(scn_conv_t op, int32_t n_slabs, int32_t ns, const float* c
                       const float* const* W /* [9] = [class][term], each [32][32] */, int32_t channels, int32_t act,
                       float* const* out /* [3] */, void* stream);
 
+/* Backward of the fused Bunch layer on the TRANSPOSED operator (rows = the layer's INPUT rows of every level, terms = the levels
+ * a row feeds; a plan created with rows_per_wave = 8):
+ *   dx_l = ( sum_j (S_{l->j}^T dz_j) W[l][j]^T ) * act'(aux_l),    dW[l][j] += aux_l^T (S_{l->j}^T dz_j)
+ *   dz[j]  device [n_slabs][rows_j][ns][32] or NULL (no gradient reaches level j)
+ *   aux[l] device: the layer's forward input of level l, or NULL (level was identically zero: nothing is computed for it)
+ *   dx[l]  device or NULL (input gradient of level l not wanted; its weight gradients are still accumulated)
+ *   W / dW: [class l][term j] = the FORWARD weight of the shift from level l to level j ([32][32], used transposed) / its gradient
+ *           (accumulated, fixed summation order), NULL where the shift does not exist. */
+size_t scn_terms_backward_workspace(scn_conv_t op_t, int32_t n_slabs, int32_t ns, int32_t channels);
+int scn_terms_backward(scn_conv_t op_t, int32_t n_slabs, int32_t ns, const float* const* dz /* [3] */,
+                       const float* const* W /* [9] */, const float* const* aux /* [3] */, int32_t channels, int32_t act,
+                       float* const* dx /* [3] */, float* const* dW /* [9] */, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)
  * returns order[new] = old that sorts the rows of every block the plan would cut by descending entry count, so the

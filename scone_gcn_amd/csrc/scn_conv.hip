@@ -42,6 +42,9 @@ int build_terms_plan(scn_conv_s* c, const uint8_t* term, const int32_t* lvl_row0
                      int group_rows);
 int terms_forward(scn_conv_s* c, int n_slabs, const float* const* x, const float* const* W, int act, float* const* out,
                   hipStream_t st);
+size_t terms_backward_workspace(const scn_conv_s* c, int n_slabs);
+int terms_backward(scn_conv_s* c, int n_slabs, const float* const* dz, const float* const* W, const float* const* aux, int act,
+                   float* const* dx, float* const* dW, void* ws, hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
@@ -429,6 +432,22 @@ int scn_terms_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* co
     for (int l = 0; l < 3; ++l)
         if (out[l] && c->terms.lvl_row0[l + 1] == c->terms.lvl_row0[l]) return SCN_ERR_BAD_SHAPE;
     return terms_forward(c, n_slabs, x, W, act, out, (hipStream_t)stream);
+}
+
+size_t scn_terms_backward_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, int32_t channels) {
+    if (!c || !c->terms.built || c->terms.group_rows != 8 || n_slabs <= 0 || ns != BK_NS || channels != 32) return 0;
+    return terms_backward_workspace(c, n_slabs);
+}
+
+int scn_terms_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const float* const* W,
+                       const float* const* aux, int32_t channels, int32_t act, float* const* dx, float* const* dW,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !dz || !W || !aux || !dx || !dW || !workspace) return SCN_ERR_BAD_ARG;
+    if (!c->terms.built) return SCN_ERR_UNSUPPORTED;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (ns != BK_NS || channels != 32 || n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < scn_terms_backward_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
+    return terms_backward(c, n_slabs, dz, W, aux, act, dx, dW, workspace, (hipStream_t)stream);
 }
 
 int scn_conv_n_slots(scn_conv_t c) { return c ? c->n_slots : SCN_ERR_BAD_ARG; }

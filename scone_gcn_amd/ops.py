@@ -390,6 +390,25 @@ class TermsOp:
         return outs
 
 
+def _terms_backward(op, dzs, Ws, auxs, act, want_dx, dWs):
+    """TermsOp.backward (kept a function so the class above stays forward-only readable): dzs[j] / auxs[l] level tensors or
+    None, Ws[l][j] / dWs[l][j] (32, 32) tensors or None, want_dx[l].  Returns the list of input gradients (None where not wanted)."""
+    lib = _lib.load()
+    ref = next(x for x in dzs if x is not None)
+    S, ns = ref.shape[0], ref.shape[2]
+    dxs = [torch.empty((S, op.sizes[l], ns, 32), device=ref.device, dtype=torch.float32) if want_dx[l] else None for l in range(3)]
+    nbytes = int(lib.scn_terms_backward_workspace(op.handle, S, ns, 32))
+    assert nbytes > 0, "terms backward not served"
+    ws = torch.empty(nbytes, device=ref.device, dtype=torch.uint8)
+    flat = lambda M: ptr_array([_dev(M[l][j]).value if M[l][j] is not None else None for l in range(3) for j in range(3)])
+    p3 = lambda L: ptr_array([_dev(t).value if t is not None else None for t in L])
+    nb = _nbytes(*[x for x in dzs if x is not None], *[x for x in auxs if x is not None], *[x for x in dxs if x is not None]) + op.csr_bytes
+    with _timed("terms_bwd c32", nb):
+        check(lib.scn_terms_backward(op.handle, S, ns, p3(dzs), flat(Ws), p3(auxs), 32, ACT[act], p3(dxs), flat(dWs),
+                                     ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "scn_terms_backward")
+    return dxs
+
+
 def _pairable(widths, ns):
     """All widths 16: two consecutive points are one 32-channel point under block-diagonal weights diag(W, W), which is the
     shape the MFMA dense-term kernels take (the same trick as the paired C=16 convolution kernels)."""
@@ -922,7 +941,9 @@ class BunchPlan:
             dev = self._dev_csr
             # bins: rows of (nodes, edges, faces) a block holds = the natural 0.37 : 1 : 0.67 proportions in wave units
             fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)}, self.layout.merged, (12, 32, 20), 4)
-            self._terms = (fwd, None)
+            bwd = TermsOp(self.sizes, {(BUNCH_SRC[k], BUNCH_DST[k]): dev[k].T.tocsr() for k in range(7)}, self.layout.merged,
+                          (16, 32, 16), 8)
+            self._terms = (fwd, bwd)
         return self._terms
 
     @staticmethod
@@ -1025,6 +1046,22 @@ class BunchPlan:
         for i in reversed(range(L)):
             x, xzero = states[i], zeros[i]
             new_dz, new_zero = [None, None, None], [True, True, True]
+            c_dz = {dz[l].shape[3] for l in range(3) if not dzero[l]}
+            c_x = {x[l].shape[3] for l in range(3) if not xzero[l] and x[l] is not None}
+            if FUSE_BUNCH and ns == NS and c_dz == {32} and c_x == {32}:
+                # fused layer backward on the transposed operator (scn_terms_backward): rows = this layer's input rows
+                dzs = [None if dzero[l] else dz[l] for l in range(3)]
+                auxs = [None if (xzero[l] or x[l] is None) else x[l] for l in range(3)]
+                Ws = [[None] * 3 for _ in range(3)]
+                dWs = [[None] * 3 for _ in range(3)]
+                for k in range(7):
+                    a, b = BUNCH_SRC[k], BUNCH_DST[k]
+                    if auxs[a] is not None and dzs[b] is not None:
+                        Ws[a][b], dWs[a][b] = weights[7 * i + k], grads[7 * i + k]
+                want = [i > 0 and auxs[l] is not None and any(w is not None for w in Ws[l]) for l in range(3)]
+                dxs = _terms_backward(self._terms_ops()[1], dzs, Ws, auxs, "relu", want, dWs)
+                dz, dzero = dxs, [d is None for d in dxs]
+                continue
             for lvl in range(3):
                 ks = [k for k in self.bwd_slots[lvl] if not dzero[BUNCH_DST[k]]]
                 if not ks or xzero[lvl]:
