@@ -976,6 +976,7 @@ class BunchPlan:
                 if need[i + 1][BUNCH_DST[k]]:
                     need[i][BUNCH_SRC[k]] = True
         states, zeros = [cur], [zero]
+        first_g = {}
         for i in range(L):
             nxt, nzero = [], []
             c_outs = {weights[7 * i + k].shape[1] for k in range(7)}
@@ -1006,6 +1007,8 @@ class BunchPlan:
                 Ws = [weights[7 * i + k] for k in ks]
                 if all(self._blocked_ok(ns, cur[BUNCH_SRC[k]].shape[3]) for k in ks):
                     Gs = [self._spmm(self.term_fwd[k], cur[BUNCH_SRC[k]]) for k in ks]
+                    if i == 0 and x.shape[3] == 1:          # the shifted 1-channel input S_k x: all the first layer's weight
+                        first_g.update(zip(ks, Gs))         # gradient needs (dW_k = sum_p (S_k x)[p] dz[p], one stream over dz)
                     nxt.append(dense_terms_forward(Gs, Ws, c_out, "relu"))
                 else:
                     fwd, _ = self._generic_ops()
@@ -1017,6 +1020,7 @@ class BunchPlan:
             states.append(cur)
             zeros.append(zero)
         self._zeros = zeros
+        self._first_g = first_g
         return states
 
     def forward(self, x, last_dev, weights):
@@ -1030,11 +1034,11 @@ class BunchPlan:
         check(lib.scn_node_readout_forward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
                                            _dev(last_dev, torch.int32), _dev(logits), _dev(logp), _stream()),
               "scn_node_readout_forward")
-        return logp, (states, self._zeros)
+        return logp, (states, self._zeros, self._first_g)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         lib = _lib.load()
-        states, zeros = saved
+        states, zeros, first_g = saved
         nodes_out = states[-1][0]
         S, V, ns, _ = nodes_out.shape
         dz = [torch.empty_like(nodes_out), None, None]
@@ -1062,6 +1066,22 @@ class BunchPlan:
                 dxs = _terms_backward(self._terms_ops()[1], dzs, Ws, auxs, "relu", want, dWs)
                 dz, dzero = dxs, [d is None for d in dxs]
                 continue
+            if i == 0 and FUSE_BUNCH and first_g and all(x[l] is None or x[l].shape[3] == 1 for l in range(3)):
+                # first layer (one 1-channel input level): the shift sits on the 1-channel side, dW_k[0][c] = sum_p (S_k x)[p] dz[p][c]
+                # -- dz of every level streamed once, no transposed SpMM, no gathered 32-channel tensor (scn_conv_dw_first)
+                done = True
+                for k, g in first_g.items():
+                    d = dz[BUNCH_DST[k]]
+                    if dzero[BUNCH_DST[k]] or d is None:
+                        continue
+                    y = torch.zeros((g.shape[0], g.shape[1], g.shape[2], Y_STRIDE), device=g.device, dtype=torch.float32)
+                    y[..., 0] = g[..., 0]
+                    dummy = [torch.zeros_like(grads[k]) for _ in range(2)]
+                    done = done and self.term_fwd[k].dw_first(None, y, d, [grads[k]] + dummy)
+                    if not done:
+                        break
+                if done:
+                    break
             for lvl in range(3):
                 ks = [k for k in self.bwd_slots[lvl] if not dzero[BUNCH_DST[k]]]
                 if not ks or xzero[lvl]:
