@@ -316,6 +316,59 @@ __global__ __launch_bounds__(256) void dense_fwd_in1_kernel(DenseFwdArgs a) {
     }
 }
 
+// every term ONE channel wide in the backward (the last Bunch layer, 32 -> 1, TE:184-192: G'_k = S_k^T dz is a scalar per point):
+//   dx[p][ca] = (sum_k g_k[p] W_k[ca][0]) * act'(aux[p][ca]),   dW_k[ca][0] += sum_p aux[p][ca] g_k[p]
+// thread = (point, 4 aux channels): aux read once, dx written once, coalesced 16-byte accesses -- a pure stream; per-thread
+// partial sums reduced per block in a fixed order.  partial layout: [block][k * c_aux + ca] (what dense_dw_reduce expects).
+struct DenseBwdG1Args {
+    int64_t n_points;
+    int32_t n_terms, c_aux, act;
+    const float* G[DN_MAX_TERMS];
+    const float* W[DN_MAX_TERMS];
+    const float* aux;
+    float* dx;
+    float* partial;
+};
+__global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
+    __shared__ f32x4 red[DN_MAX_TERMS * 256];
+    const int cg = a.c_aux / 4;                                     // 256 % cg == 0 (c_aux in {16, 32, 64})
+    const int cq = threadIdx.x % cg;
+    f32x4 w[DN_MAX_TERMS], acc[DN_MAX_TERMS];
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k) {
+        w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t total = a.n_points * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pnt = i / cg;
+        const f32x4 x = *(const f32x4*)(a.aux + i * 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < DN_MAX_TERMS; ++k)
+            if (k < a.n_terms) {
+                const float g = a.G[k][pnt];
+                v += g * w[k];
+                acc[k] += g * x;
+            }
+        if (a.dx) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(a.act, x[j]);
+            __builtin_nontemporal_store(v, (f32x4*)(a.dx + i * 4));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DN_MAX_TERMS; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_terms * cg) {                        // threads with equal tid % cg hold the same channels
+        const int k = threadIdx.x / cg, q = threadIdx.x - k * cg;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int t = q; t < 256; t += cg) sum += red[k * 256 + t];
+        float* o = a.partial + (size_t)blockIdx.x * (a.n_terms * a.c_aux) + k * a.c_aux + q * 4;
+        o[0] = sum[0]; o[1] = sum[1]; o[2] = sum[2]; o[3] = sum[3];
+    }
+}
+
 struct DenseReduceArgs {
     const float* partial;
     int32_t n_partials, total, n_terms;
@@ -399,7 +452,7 @@ size_t scn_dense_terms_backward_workspace(int64_t n_points, int32_t n_terms, con
     if (!c || n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS) return 0;
     size_t tot = 0;
     for (int k = 0; k < n_terms; ++k) tot += (size_t)c_aux * c[k];
-    return (size_t)dense_blocks(n_points) * tot * sizeof(float) + 256;
+    return (size_t)std::max(dense_blocks(n_points), 1024) * tot * sizeof(float) + 256;   // (1024: the rank-one streaming kernel's grid)
 }
 
 int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* const* G, const int32_t* c,
@@ -424,8 +477,24 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
         r.off[k + 1] = r.off[k] + c_aux * c[k];
         r.dW[k] = dW[k];
     }
-    const int nb = dense_blocks(n_points);
     hipStream_t st = (hipStream_t)stream;
+    bool all1 = c_aux == 16 || c_aux == 32 || c_aux == 64;
+    for (int k = 0; k < n_terms; ++k) all1 = all1 && c[k] == 1;
+    if (all1) {                                                     // rank-one terms: the streaming kernel
+        DenseBwdG1Args g;
+        std::memset(&g, 0, sizeof(g));
+        g.n_points = n_points; g.n_terms = n_terms; g.c_aux = c_aux; g.act = act; g.aux = aux; g.dx = dx;
+        g.partial = (float*)workspace;
+        for (int k = 0; k < n_terms; ++k) { g.G[k] = G[k]; g.W[k] = W[k]; }
+        const int nbs = (int)std::min<int64_t>(1024, (n_points * (c_aux / 4) + 255) / 256);
+        hipLaunchKernelGGL(dense_bwd_g1_kernel, dim3(nbs), dim3(256), 0, st, g);
+        SCN_LAUNCH_CHECK();
+        r.partial = g.partial; r.n_partials = nbs; r.total = r.off[n_terms]; r.n_terms = n_terms;
+        hipLaunchKernelGGL(dense_dw_reduce, dim3((r.total + 255) / 256), dim3(256), 0, st, r);
+        SCN_LAUNCH_CHECK();
+        return SCN_OK;
+    }
+    const int nb = dense_blocks(n_points);
     bool all32 = c_aux == 32;
     for (int k = 0; k < n_terms; ++k) all32 = all32 && c[k] == 32;
     if (all32) {
