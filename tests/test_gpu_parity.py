@@ -704,3 +704,71 @@ def test_fused_first_layer_gradient_equals_the_separate_kernels(mode):
     gmax = max(np.abs(b).max() for b in res[False][1])
     for a, b in zip(res[True][1], res[False][1]):
         assert np.abs(a - b).max() <= 2e-6 * gmax
+
+
+@pytest.mark.parametrize("drop", [None, "zero_nodes_in", "no_faces_out"])
+def test_fused_bunch_layer_operator_matches_scipy(drop):
+    """scn_terms_forward / scn_terms_backward (the seven Bunch shifts as one operator on the concatenated row space, blocks =
+    patches across the three levels) on random slabs against scipy: out_l = relu(sum_j (S_{j->l} x_j) W[l][j]) for the three
+    levels, and on the transposed operator dx_l = (sum_j (S^T dz_j) W[l][j]^T) relu'(aux_l), dW[l][j] = aux_l^T (S^T dz_j) --
+    including a level that is identically zero on input and a level that is not wanted on output."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(2500)
+    sc = SimplicialComplex(cx)
+    shifts, nbr, _ = te.setup_from_complex(sc, "bunch")
+    plan = ops.get_bunch_plan(shifts, nbr, ops.default_device())
+    fwd, bwd = plan._terms_ops()
+    assert fwd.plan_info()[0] > 0 and fwd.plan_info()[1] < 4.0           # patches: few staged sources per row
+    S, sizes = 3, plan.sizes
+    rs = np.random.RandomState(2)
+    dev = [s.device_csr().astype(np.float64) for s in shifts]
+    SRC, DST = ops.BUNCH_SRC, ops.BUNCH_DST
+    xs = [rs.randn(S, n, 4, 32).astype(np.float32) for n in sizes]
+    Wk = [(0.2 * rs.randn(32, 32)).astype(np.float32) for _ in range(7)]
+    live_in = [drop != "zero_nodes_in", True, True]
+    want = [True, True, drop != "no_faces_out"]
+
+    def shift(m, x):                                                     # (rows_dst x rows_src) @ [S, rows_src, 4, 32]
+        Sx, R = x.shape[0], x.shape[1]
+        y = m @ x.transpose(1, 0, 2, 3).reshape(R, -1).astype(np.float64)
+        return y.reshape(m.shape[0], Sx, 4, 32).transpose(1, 0, 2, 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xt = [t(x) if live_in[l] else None for l, x in enumerate(xs)]
+    Ws = [[None] * 3 for _ in range(3)]
+    for k in range(7):
+        if live_in[SRC[k]]:
+            Ws[DST[k]][SRC[k]] = t(Wk[k])
+    outs = fwd.forward(xt, Ws, "relu", want)
+    for l in range(3):
+        if not want[l]:
+            assert outs[l] is None
+            continue
+        ref = sum(shift(dev[k], xs[SRC[k]]) @ Wk[k].astype(np.float64) for k in range(7) if DST[k] == l and live_in[SRC[k]])
+        ref = np.maximum(ref, 0)
+        assert _maxdiff(outs[l].cpu().numpy(), ref) <= 2e-5
+    # backward on the transposed operator: rows = input rows of level a, terms = target levels b
+    dzs = [rs.randn(S, n, 4, 32).astype(np.float32) if want[l] else None for l, n in enumerate(sizes)]
+    auxs = [np.maximum(rs.randn(S, n, 4, 32), 0).astype(np.float32) if live_in[l] else None for l, n in enumerate(sizes)]
+    Wb = [[None] * 3 for _ in range(3)]
+    dWb = [[None] * 3 for _ in range(3)]
+    for k in range(7):
+        a, b = SRC[k], DST[k]
+        if auxs[a] is not None and dzs[b] is not None:
+            Wb[a][b], dWb[a][b] = t(Wk[k]), torch.full((32, 32), 0.5, device="cuda")
+    wantdx = [auxs[l] is not None and any(w is not None for w in Wb[l]) for l in range(3)]
+    dxs = ops._terms_backward(bwd, [t(d) if d is not None else None for d in dzs], Wb,
+                              [t(a) if a is not None else None for a in auxs], "relu", wantdx, dWb)
+    for a in range(3):
+        if not wantdx[a]:
+            assert dxs[a] is None
+            continue
+        gk = {k: shift(dev[k].T.tocsr(), dzs[DST[k]]) for k in range(7) if SRC[k] == a and dzs[DST[k]] is not None}
+        ref = sum(gk[k] @ Wk[k].astype(np.float64).T for k in gk) * (auxs[a] > 0)
+        assert _maxdiff(dxs[a].cpu().numpy(), ref) <= 2e-5
+        for k in gk:
+            refw = np.einsum("srnc,srnd->cd", auxs[a].astype(np.float64), gk[k]) + 0.5
+            assert _maxdiff(dWb[a][DST[k]].cpu().numpy(), refw) <= 2e-5 * max(1.0, np.abs(refw).max())
