@@ -1879,7 +1879,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             const bool more = vdma < n_vis;
             const char* Xn = src_base(more ? vdma : it);
             char* nbuf = sm.buf(vdma & 1);
-            auto side = [&](int k) {
+            auto side = [&](int k) {                                     // (all eight right after the barrier instead: +2 %)
                 if (k < NDMA && more) dma_k(k, Xn, nbuf);
             };
             // Per segment g: [transpose + dgrad] over its two k-steps, then straight into dW_g.  The transpose keeps the three
