@@ -274,6 +274,17 @@ __device__ __forceinline__ int swz16(int slot, int chunk) { return chunk ^ (slot
 
 // ---- C = 32 (512-byte pieces): LDS carve with 16-bit pre-encoded ELL slots, and the gather built on it ----
 // [buf0][buf1][ell_v: BK_ELL_CAP float2][srcrows: BK_SRC i32][enc: BK_ELL_CAP u16][self: BK_R u8][extra]
+// streamed tensors of the backward (aux read once, dx written once per launch): non-temporal, so that the L2 keeps the staged
+// halo rows neighbouring blocks share: -1.4 % (SCN_NO_NT: plain accesses, for A/B runs).  The forward's output stores are
+// left plain: non-temporal they cost it 1-3 %.
+#ifdef SCN_NO_NT
+#define SCN_ST_STREAM(ptr, val) (*(ptr) = (val))
+#define SCN_LD_STREAM(ptr) (*(ptr))
+#else
+#define SCN_ST_STREAM(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define SCN_LD_STREAM(ptr) __builtin_nontemporal_load(ptr)
+#endif
+
 struct SmemC32 {
     char* buf0;
     __device__ __forceinline__ char* buf(int i) const { return buf0 + i * (BK_SRC * 512); }
@@ -1843,7 +1854,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = 2 * (r >> 2) + h < rows_left && lane_live;
-                const float v = ap[ok ? L0 + ((r & 3) + 8 * (r >> 2)) * CH : 0];
+                const float v = SCN_LD_STREAM(ap + (ok ? L0 + ((r & 3) + 8 * (r >> 2)) * CH : 0));
                 a[r] = ok ? v : 0.f;
             }
             // FIRST: the tile's y records, one float per lane and register, placed for a ds_swizzle broadcast inside each half wave:
@@ -1952,7 +1963,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                  bl = __builtin_bit_cast(bf16x8, pl);
                     const Split3& at = At[t];
                     auto store = [&](int r) {                            // only in the last segment: acc is complete there
-                        if (!FIRST && u == 2 && dp && 2 * (r >> 2) + h < rows_left) dp[L0 + ((r & 3) + 8 * (r >> 2)) * CH] = acc[r];
+                        if (!FIRST && u == 2 && dp && 2 * (r >> 2) + h < rows_left) SCN_ST_STREAM(dp + L0 + ((r & 3) + 8 * (r >> 2)) * CH, acc[r]);
                     };
                     const int r0 = 8 * t;
                     dWacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.lo, bh, dWacc[g], 0, 0, 0);
