@@ -665,6 +665,45 @@ def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
     assert 0.0 <= t2 <= 1.0
 
 
+def test_train_loop_with_empty_batches(cfg1, sc1):
+    """Batch masks that select no training sample (batch size 1 and a drawn test sample: steps 0, 1, 6 and 12 of this stream).
+    The reference divides by the empty mask's sum there (STM:54) and poisons the weights with NaN; the mirror skips that gradient
+    step and nothing else: the Adam step index stays the loop index (STM:306-310), the epoch-end evaluation still runs."""
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    stm.reseed(1030)
+    N, bs, epochs = 12, 1, 2
+    sel = np.arange(N)
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    inputs = [readout, cfg1["last_nodes"][sel], cfg1["flows"][sel]]
+    y, train_mask, test_mask = cfg1["targets"][sel], cfg1["train_mask"][sel], cfg1["test_mask"][sel]
+    n_nbrs = sc1.n_nbrs(inputs[1])
+    net = stm.Scone_GCN(epochs, 1e-3, bs, 5e-5, verbose=False)
+    net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, train_mask, model_type="scone")
+    res = net.train(inputs, y, train_mask, test_mask, n_nbrs)
+
+    rs = np.random.RandomState(1030)
+    w = [(0.01 * rs.randn(*s)).astype(np.float32).astype(np.float64) for s in so.weight_shapes(1, [(3, 16)] * 3, 1)]
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, "scone")
+    adam = so.Adam(w, 1e-3)
+    n_batches = int(train_mask.sum()) // bs
+    empties = []
+    for i in range(epochs * n_batches):
+        bm = so.draw_batch_mask(rs, N, bs, train_mask)
+        if int(bm.sum()) == 0:
+            empties.append(i)
+            continue
+        _, g = so.scone_loss_and_grad(adam.x, shifts_o[0], shifts_o[1], Bc, inputs[1], X, y, bm, 5e-5)
+        adam.update(i, g)
+    assert empties and empties[0] == 0 and (epochs * n_batches - 1) not in empties      # the case this test is about
+    for a, b in zip(net.weights, adam.x):
+        assert np.isfinite(a.cpu().numpy()).all() and _maxdiff(a.cpu().numpy(), b) <= 5e-6
+    out = so.scone_forward(adam.x, shifts_o[0], shifts_o[1], Bc, inputs[1], X)
+    assert all(r is not None and np.isfinite(r) for r in res)
+    assert abs(res[0] - so.loss_from_preds(out, y, train_mask, adam.x, 5e-5)) <= 1e-5
+    assert abs(res[2] - so.loss_from_preds(out, y, test_mask, adam.x, 5e-5)) <= 1e-5
+
+
 @pytest.mark.parametrize("mode", ["dense", "zeros"])
 def test_fused_first_layer_gradient_equals_the_separate_kernels(mode):
     """scn_conv_backward_fused_first (layer 1's backward contracts its input gradient with the shifted input y in registers and
