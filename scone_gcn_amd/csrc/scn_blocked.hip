@@ -473,40 +473,72 @@ constexpr int SP_THREADS = 1024;
 constexpr int SP_ITEMS = 2;           // BK_R * 32 chunks / SP_THREADS
 constexpr int SP_SLAB_GROUP = 8;      // slabs a workgroup processes per visit of a block
 
-__device__ __forceinline__ void dma_stage_sp(const char* Xs, char* buf, const Smem& sm, int nsrc, int piece, int cpp) {
+// A staged piece of the two-buffer SpMM is VIRTUAL: `batch` consecutive slabs of one source row side by side (K floats
+// each, cpk = K/4 chunks), so that a narrow operand -- the 1-channel tensors of the first / last Bunch layer are K = 4 floats
+// per row and slab: 64 work items per block -- fills the workgroup: chunk pos of a piece = chunk pos % cpk of slab pos / cpk.
+// batch = 1 is the plain layout.
+__device__ __forceinline__ void dma_stage_sp(const char* X, int slab0, int n_avail, size_t slab_bytes, char* buf, const Smem& sm,
+                                             int nsrc, int k4, int cpk, int vcpp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int total = nsrc * cpp;
+    const int total = nsrc * vcpp;
     for (int base = wave * 64; base < total; base += SP_THREADS) {
         const int c = base + lane;
         if (c < total) {
-            const int slot = c / cpp, pos = c - slot * cpp;
-            const char* g = Xs + (size_t)sm.srcrows[slot] * piece + pos * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+            const int slot = c / vcpp, pos = c - slot * vcpp;
+            const int sl = pos / cpk, sub = pos - sl * cpk;
+            if (sl < n_avail) {
+                const char* g = X + (size_t)(slab0 + sl) * slab_bytes + (size_t)sm.srcrows[slot] * k4 + sub * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+            }
         }
     }
+}
+
+// (plain pieces of one slab at Xs)
+__device__ __forceinline__ void dma_stage_sp(const char* Xs, char* buf, const Smem& sm, int nsrc, int piece, int cpp) {
+    dma_stage_sp(Xs, 0, 1, 0, buf, sm, nsrc, piece, cpp, cpp);
 }
 
 template <bool DUAL>
 __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, const float* __restrict__ X,
                                                                      float* __restrict__ ya, float* __restrict__ yb,
-                                                                     int n_rows, int n_cols, int n_slabs, int K) {
+                                                                     int n_rows, int n_cols, int n_slabs, int K, int batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int piece = K * 4, cpp = K / 4;
+    const int k4 = K * 4, cpk = K / 4;                              // one slab's piece
+    const int piece = k4 * batch, cpp = cpk * batch;                // the staged (virtual) piece
+    const size_t in_slab_bytes = (size_t)n_cols * k4;
     const Smem sm = carve(smem, piece);
     uint8_t* tws = (uint8_t*)(smem + smem_bytes(piece));           // [BK_WAVES] per-row-group widths
     int b0, b_end, b_stride;
     block_range(P.n_blocks, b0, b_end, b_stride);
-    const int slab_lo = (int)((int64_t)blockIdx.y * n_slabs / gridDim.y), slab_hi = (int)((int64_t)(blockIdx.y + 1) * n_slabs / gridDim.y);
-    if (slab_lo >= slab_hi) return;
+    const int n_units = (n_slabs + batch - 1) / batch;              // a unit = `batch` slabs (the last one may hold fewer)
+    const int unit_lo = (int)((int64_t)blockIdx.y * n_units / gridDim.y), unit_hi = (int)((int64_t)(blockIdx.y + 1) * n_units / gridDim.y);
+    if (unit_lo >= unit_hi) return;
     f32x4 pa[SP_ITEMS], pb[SP_ITEMS];
-    size_t pend_off = 0;
+    int pend_slab0 = 0, pend_row0 = 0, pend_avail = 0;
     int pend_total = -1;
-    // slab groups outside, blocks inside: all workgroups sweep their blocks for the same 8 slabs before moving on, which
+    auto store_pending = [&]() {
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; ++k) {
+            const int idx = threadIdx.x + k * SP_THREADS;
+            if (idx < pend_total) {
+                const int r = idx / cpp, ch = idx - r * cpp;
+                const int sl = ch / cpk, sub = ch - sl * cpk;
+                if (sl < pend_avail) {
+                    const size_t off = ((size_t)(pend_slab0 + sl) * n_rows + pend_row0 + r) * K + sub * 4;
+                    // non-temporal: the outputs would otherwise evict the halo rows neighbouring blocks are about to read
+                    __builtin_nontemporal_store(pa[k], (f32x4*)(ya + off));
+                    if (DUAL) __builtin_nontemporal_store(pb[k], (f32x4*)(yb + off));
+                }
+            }
+        }
+    };
+    // unit groups outside, blocks inside: all workgroups sweep their blocks for the same 8 slabs before moving on, which
     // keeps more of the halo rows that neighbouring blocks share within reach of the caches (-4 % at |E| = 1M; 4 or 16
     // slabs per group are worse, and so is giving a workgroup a contiguous block range)
-    for (int slab0 = slab_lo; slab0 < slab_hi; slab0 += SP_SLAB_GROUP)
-    for (int bi = b0, slab1 = min(slab0 + SP_SLAB_GROUP, slab_hi); bi < b_end; bi += b_stride) {
+    for (int u0 = unit_lo; u0 < unit_hi; u0 += SP_SLAB_GROUP)
+    for (int bi = b0, u1 = min(u0 + SP_SLAB_GROUP, unit_hi); bi < b_end; bi += b_stride) {
         const int b = P.assign ? P.assign[bi] : bi;
         wait_all_and_barrier();
         BlockMeta m;
@@ -527,24 +559,15 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
         __syncthreads();
         const int total = m.rows * cpp;
         const bool wave_uniform_rows = cpp >= 8 && (64 % cpp) == 0;
-        dma_stage_sp((const char*)X + (size_t)slab0 * n_cols * piece, sm.buf(0), sm, m.nsrc, piece, cpp);
-        for (int slab = slab0; slab < slab1; ++slab) {
-            const int cur_off = ((slab - slab0) & 1) * sm.buf_stride;
+        auto avail = [&](int u) { return min(batch, n_slabs - u * batch); };
+        dma_stage_sp((const char*)X, u0 * batch, avail(u0), in_slab_bytes, sm.buf(0), sm, m.nsrc, k4, cpk, cpp);
+        for (int u = u0; u < u1; ++u) {
+            const int cur_off = ((u - u0) & 1) * sm.buf_stride;
             wait_vm_and_barrier();
-            if (slab + 1 < slab1)
-                dma_stage_sp((const char*)X + (size_t)(slab + 1) * n_cols * piece, sm.buf((slab + 1 - slab0) & 1), sm, m.nsrc,
-                             piece, cpp);
-            if (pend_total >= 0) {
-#pragma unroll
-                for (int k = 0; k < SP_ITEMS; ++k) {
-                    const int idx = threadIdx.x + k * SP_THREADS;
-                    if (idx < pend_total) {
-                        // non-temporal: the outputs would otherwise evict the halo rows neighbouring blocks are about to read
-                        __builtin_nontemporal_store(pa[k], (f32x4*)(ya + pend_off + (size_t)idx * 4));
-                        if (DUAL) __builtin_nontemporal_store(pb[k], (f32x4*)(yb + pend_off + (size_t)idx * 4));
-                    }
-                }
-            }
+            if (u + 1 < u1)
+                dma_stage_sp((const char*)X, (u + 1) * batch, avail(u + 1), in_slab_bytes, sm.buf((u + 1 - u0) & 1), sm, m.nsrc, k4,
+                             cpk, cpp);
+            if (pend_total >= 0) store_pending();
 #pragma unroll
             for (int k = 0; k < SP_ITEMS; ++k) {
                 const int idx = threadIdx.x + k * SP_THREADS;
@@ -569,20 +592,13 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_blocked_kernel(PlanDev P, 
                 pa[k] = a0;
                 pb[k] = a1;
             }
-            pend_off = ((size_t)slab * n_rows + m.row0) * K;
+            pend_slab0 = u * batch;
+            pend_avail = avail(u);
+            pend_row0 = m.row0;
             pend_total = total;
         }
     }
-    if (pend_total >= 0) {
-#pragma unroll
-        for (int k = 0; k < SP_ITEMS; ++k) {
-            const int idx = threadIdx.x + k * SP_THREADS;
-            if (idx < pend_total) {
-                __builtin_nontemporal_store(pa[k], (f32x4*)(ya + pend_off + (size_t)idx * 4));
-                if (DUAL) __builtin_nontemporal_store(pb[k], (f32x4*)(yb + pend_off + (size_t)idx * 4));
-            }
-        }
-    }
+    if (pend_total >= 0) store_pending();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2922,14 +2938,22 @@ int blocked_spmm(scn_conv_s* c, int n_slabs, int k, const float* x, float* ya, f
         SCN_LAUNCH_CHECK();
         return SCN_OK;
     }
-    SCN_ENSURE_LDS(spmm_blocked_kernel<true>, lds);
-    SCN_ENSURE_LDS(spmm_blocked_kernel<false>, lds);
+    // narrow operands: fold consecutive slabs into one staged piece (see dma_stage_sp) until it is 128 floats wide
+    static const bool no_batch = getenv("SCN_SPMM_NO_BATCH") != nullptr;        // A/B switch
+    const int batch = (no_batch || k > 32) ? 1 : std::max(1, std::min(n_slabs, 128 / k));
+    const size_t ldsb = smem_bytes(k * 4 * batch, 16);
+    if (batch > 1) {
+        launch_grid(c, (n_slabs + batch - 1) / batch, ldsb, grid);
+        P.assign = balanced_assignment(c, grid.x);
+    }
+    SCN_ENSURE_LDS(spmm_blocked_kernel<true>, ldsb);
+    SCN_ENSURE_LDS(spmm_blocked_kernel<false>, ldsb);
     if (yb)
-        hipLaunchKernelGGL(spmm_blocked_kernel<true>, grid, dim3(SP_THREADS), lds, st, P, x, ya, yb, c->n_rows, c->g[0].n_cols,
-                           n_slabs, k);
+        hipLaunchKernelGGL(spmm_blocked_kernel<true>, grid, dim3(SP_THREADS), ldsb, st, P, x, ya, yb, c->n_rows, c->g[0].n_cols,
+                           n_slabs, k, batch);
     else
-        hipLaunchKernelGGL(spmm_blocked_kernel<false>, grid, dim3(SP_THREADS), lds, st, P, x, ya, yb, c->n_rows,
-                           c->g[0].n_cols, n_slabs, k);
+        hipLaunchKernelGGL(spmm_blocked_kernel<false>, grid, dim3(SP_THREADS), ldsb, st, P, x, ya, yb, c->n_rows,
+                           c->g[0].n_cols, n_slabs, k, batch);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
