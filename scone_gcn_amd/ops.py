@@ -1005,6 +1005,16 @@ class BunchPlan:
                     nzero.append(True)
                     continue
                 Ws = [weights[7 * i + k] for k in ks]
+                if (FUSE_BUNCH and c_out == 1 and all(cur[BUNCH_SRC[k]].shape[3] > 1 for k in ks)
+                        and self._blocked_ok(ns, 1)):
+                    # one output channel (the last layer): project FIRST, then shift -- (S_k X_k) W_k = S_k (X_k W_k): every
+                    # input level is read once and the shifts run on 1-channel tensors
+                    ys = [dense_terms_forward([cur[BUNCH_SRC[k]]], [w], 1, "none") for k, w in zip(ks, Ws)]
+                    Gs = [self._spmm(self.term_fwd[k], y) for k, y in zip(ks, ys)]
+                    one = torch.ones((1, 1), device=x.device, dtype=torch.float32)
+                    nxt.append(dense_terms_forward(Gs, [one] * len(Gs), 1, "relu"))
+                    nzero.append(False)
+                    continue
                 if all(self._blocked_ok(ns, cur[BUNCH_SRC[k]].shape[3]) for k in ks):
                     Gs = [self._spmm(self.term_fwd[k], cur[BUNCH_SRC[k]]) for k in ks]
                     if i == 0 and x.shape[3] == 1:          # the shifted 1-channel input S_k x: all the first layer's weight
