@@ -292,6 +292,15 @@ int scn_terms_backward(scn_conv_t op_t, int32_t n_slabs, int32_t ns, const float
                        const float* const* W /* [9] */, const float* const* aux /* [3] */, int32_t channels, int32_t act,
                        float* const* dx /* [3] */, float* const* dW /* [9] */, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The same backward for the layer that FOLLOWS the 1-channel first layer of bunch_func (TE:179-195): its input gradient is the
+ * gradient of the first layer's pre-activation and is needed for the first layer's weight gradient only, so it is contracted
+ * with the first layer's shifted input inside the kernel and never written:
+ *   dW_first[l][c] += sum_p y_l[p] * dx_l[p][c],   y_l = S_{1->l} x, device [n_slabs][rows_l][ns] (one float per point) or NULL
+ *   dW_first[l] device [32] (the (1, 32) weight of the shift into level l) or NULL.  dW as above; same workspace size. */
+int scn_terms_backward_fused_first(scn_conv_t op_t, int32_t n_slabs, int32_t ns, const float* const* dz /* [3] */,
+                                   const float* const* W /* [9] */, const float* const* aux /* [3] */, int32_t channels,
+                                   int32_t act, const float* const* y /* [3] */, float* const* dW /* [9] */,
+                                   float* const* dW_first /* [3] */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Host-only layout helper (no device work, no reference counterpart: the reference's dense operators, TE:240-257, have
  * no storage order).  For a SQUARE CSR pattern (rows and columns share one index space, e.g. L_lower in device order)

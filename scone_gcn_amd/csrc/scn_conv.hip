@@ -44,7 +44,7 @@ int terms_forward(scn_conv_s* c, int n_slabs, const float* const* x, const float
                   hipStream_t st);
 size_t terms_backward_workspace(const scn_conv_s* c, int n_slabs);
 int terms_backward(scn_conv_s* c, int n_slabs, const float* const* dz, const float* const* W, const float* const* aux, int act,
-                   float* const* dx, float* const* dW, void* ws, hipStream_t st);
+                   float* const* dx, float* const* dW, const float* const* y, float* const* dW_first, void* ws, hipStream_t st);
 bool blocked_dw_first_supported(const scn_conv_s* c, int ns, int cd);
 size_t blocked_dw_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int cd);
 int blocked_dw_first(scn_conv_s* c, int n_slabs, const float* x, const float* y, const float* dz, int cd,
@@ -447,7 +447,20 @@ int scn_terms_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* c
     if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     if (ns != BK_NS || channels != 32 || n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
     if (workspace_bytes < scn_terms_backward_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
-    return terms_backward(c, n_slabs, dz, W, aux, act, dx, dW, workspace, (hipStream_t)stream);
+    return terms_backward(c, n_slabs, dz, W, aux, act, dx, dW, nullptr, nullptr, workspace, (hipStream_t)stream);
+}
+
+int scn_terms_backward_fused_first(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const float* const* W,
+                                   const float* const* aux, int32_t channels, int32_t act, const float* const* y, float* const* dW,
+                                   float* const* dW_first, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !dz || !W || !aux || !y || !dW || !dW_first || !workspace) return SCN_ERR_BAD_ARG;
+    if (!c->terms.built) return SCN_ERR_UNSUPPORTED;
+    if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (ns != BK_NS || channels != 32 || n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < scn_terms_backward_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
+    for (int l = 0; l < 3; ++l)
+        if ((y[l] == nullptr) != (dW_first[l] == nullptr)) return SCN_ERR_BAD_ARG;
+    return terms_backward(c, n_slabs, dz, W, aux, act, nullptr, dW, y, dW_first, workspace, (hipStream_t)stream);
 }
 
 int scn_conv_n_slots(scn_conv_t c) { return c ? c->n_slots : SCN_ERR_BAD_ARG; }

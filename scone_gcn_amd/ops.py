@@ -409,6 +409,25 @@ def _terms_backward(op, dzs, Ws, auxs, act, want_dx, dWs):
     return dxs
 
 
+def _terms_backward_first(op, dzs, Ws, auxs, act, ys, dWs, dWs_first):
+    """_terms_backward for the layer that follows the 1-channel first layer: no input gradients come back -- they are contracted
+    with the first layer's shifted input ys[l] (S, rows_l, ns, 1) into dWs_first[l] (1, 32) inside the kernel
+    (scn_terms_backward_fused_first)."""
+    lib = _lib.load()
+    ref = next(x for x in dzs if x is not None)
+    S, ns = ref.shape[0], ref.shape[2]
+    nbytes = int(lib.scn_terms_backward_workspace(op.handle, S, ns, 32))
+    assert nbytes > 0, "terms backward not served"
+    ws = torch.empty(nbytes, device=ref.device, dtype=torch.uint8)
+    flat = lambda M: ptr_array([_dev(M[l][j]).value if M[l][j] is not None else None for l in range(3) for j in range(3)])
+    p3 = lambda L: ptr_array([_dev(t).value if t is not None else None for t in L])
+    nb = _nbytes(*[x for x in dzs if x is not None], *[x for x in auxs if x is not None], *[x for x in ys if x is not None]) + op.csr_bytes
+    with _timed("terms_bwd c32 + dW_first", nb):
+        check(lib.scn_terms_backward_fused_first(op.handle, S, ns, p3(dzs), flat(Ws), p3(auxs), 32, ACT[act], p3(ys), flat(dWs),
+                                                 p3(dWs_first), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+              "scn_terms_backward_fused_first")
+
+
 def _pairable(widths, ns):
     """All widths 16: two consecutive points are one 32-channel point under block-diagonal weights diag(W, W), which is the
     shape the MFMA dense-term kernels take (the same trick as the paired C=16 convolution kernels)."""
@@ -1073,6 +1092,15 @@ class BunchPlan:
                     if auxs[a] is not None and dzs[b] is not None:
                         Ws[a][b], dWs[a][b] = weights[7 * i + k], grads[7 * i + k]
                 want = [i > 0 and auxs[l] is not None and any(w is not None for w in Ws[l]) for l in range(3)]
+                # the layer after the 1-channel first layer: its input gradients feed the first layer's weight gradient and nothing
+                # else -- contracted with the shifted input S_k x inside the kernel, never written (dW_k[0][c] = sum_p (S_k x)[p] dx[p][c])
+                k_of = {BUNCH_DST[k]: k for k in first_g}
+                if (i == 1 and FUSE_FIRST and first_g and all(not want[l] or l in k_of for l in range(3))
+                        and all(first_g[k].shape[3] == 1 and weights[k].shape == (1, 32) for k in first_g)):
+                    ys = [first_g[k_of[l]].contiguous() if (want[l] and l in k_of) else None for l in range(3)]
+                    dWf = [grads[k_of[l]] if ys[l] is not None else None for l in range(3)]
+                    _terms_backward_first(self._terms_ops()[1], dzs, Ws, auxs, "relu", ys, dWs, dWf)
+                    break
                 dxs = _terms_backward(self._terms_ops()[1], dzs, Ws, auxs, "relu", want, dWs)
                 dz, dzero = dxs, [d is None for d in dxs]
                 continue

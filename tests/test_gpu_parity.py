@@ -155,7 +155,12 @@ def test_bunch_matches_oracle(cfg1, sc1, hidden):
     m = torch.as_tensor(mask, device="cuda").bool()
     yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
     loss = -(out[m] * yt[m]).sum() / m.sum()
-    loss.backward()
+    from scone_gcn_amd import ops
+    with ops.KernelTimer() as kt:
+        loss.backward()
+    if hidden == 32 and ops.FUSE_BUNCH and ops.FUSE_FIRST:
+        # the layer after the first one ran scn_terms_backward_fused_first (its input gradient is never written), the next one the plain fused backward
+        assert {"terms_bwd c32 + dW_first", "terms_bwd c32"} <= set(kt.summary())
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
