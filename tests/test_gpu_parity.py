@@ -166,6 +166,34 @@ def test_bunch_matches_oracle(cfg1, sc1, hidden):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
 
 
+def test_bunch_fused_first_gradient_equals_the_separate_kernels(cfg1, sc1):
+    """scn_terms_backward_fused_first (the second layer's backward contracts its input gradient with the first layer's shifted
+    input and never writes it) against scn_terms_backward + scn_conv_dw_first on the same batch: all 28 weight gradients."""
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(300, 322)
+    w = _rand_weights(so.weight_shapes(1, [(7, 32)] * 3, 1, "bunch"), 0.4, 3)
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
+    yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
+    grads = {}
+    keep = ops.FUSE_FIRST
+    try:
+        for fused in (True, False):
+            ops.FUSE_FIRST = fused
+            wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+            out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+            with ops.KernelTimer() as kt:
+                (-(out * yt).sum() / len(sel)).backward()
+            assert ("terms_bwd c32 + dW_first" in kt.summary()) == fused
+            grads[fused] = [t.grad.cpu().numpy().astype(np.float64) for t in wt]
+    finally:
+        ops.FUSE_FIRST = keep
+    for k, (a, b) in enumerate(zip(grads[True], grads[False])):
+        assert _maxdiff(a, b) <= 2e-6 * max(1.0, np.abs(b).max()), "weight %d" % k
+    assert max(np.abs(g).max() for g in grads[True][:7]) > 1e-4           # the first layer's gradients are not trivially zero
+
+
 def test_spmm_dual_matches_scipy(cfg1, sc1):
     from scone_gcn_amd import ops
     shifts = sc1.scone_shifts()
