@@ -1739,6 +1739,23 @@ __device__ __forceinline__ void first_dw_tile(std::integer_sequence<int, Rs...>,
     (first_dw_step<Rs>(yv0, yv1, dx[Rs], dwf), ...);
 }
 
+// PAIR form of the broadcast: a half wave is two 16-lane groups (slab A's channels, slab B's), each with its own points' y;
+// lane 16 s + j of register q holds value 16 q + j of its slab's 48 values [r][g]; and = 0x10 keeps a lane in its group.
+template <int R>
+__device__ __forceinline__ void first_dw_step_pair(const float (&yv)[3], float dx, float (&dwf)[3]) {
+#define SCN_SWZ_PAIR(G) \
+    __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(yv[(3 * R + G) / 16]), 0x10 | (((3 * R + G) % 16) << 5)))
+    dwf[0] = fmaf(SCN_SWZ_PAIR(0), dx, dwf[0]);
+    dwf[1] = fmaf(SCN_SWZ_PAIR(1), dx, dwf[1]);
+    dwf[2] = fmaf(SCN_SWZ_PAIR(2), dx, dwf[2]);
+#undef SCN_SWZ_PAIR
+}
+template <int... Rs>
+__device__ __forceinline__ void first_dw_tile_pair(std::integer_sequence<int, Rs...>, const float (&yv)[3], const f32x16& dx,
+                                                   float (&dwf)[3]) {
+    (first_dw_step_pair<Rs>(yv, dx[Rs], dwf), ...);
+}
+
 // FIRST: this layer's input is the FIRST layer's output (aux = H1 = act(y . W_first), y = the shifted 1-channel input saved by
 // scn_conv_forward_first).  The input gradient dx = dL/d(pre-activation of layer 1) is then needed for one thing only -- the
 // first layer's weight gradient dW_first[g][c] = sum_p y[p][g] dx[p][c] -- so it is contracted with y right here, in registers
@@ -1756,7 +1773,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                                                                      float* __restrict__ partial_first = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!(EXT0 && PAIR), "the power form exists for C = 32 only");
-    static_assert(!FIRST || (!EXT0 && !PAIR), "the fused first-layer gradient exists for the plain C = 32 form");
+    static_assert(!FIRST || !EXT0, "the fused first-layer gradient exists for the plain forms (C = 32, and C = 16 on slab pairs)");
     constexpr int PIECE = 512, CPP = 32, NDMA = BK_SRC * CPP / BK_THREADS;
     constexpr int CH = PAIR ? 16 : 32;                       // channels of a stored point
     const SmemC32 sm = carve_c32(smem);
@@ -1876,11 +1893,21 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
             // FIRST: the tile's y records, one float per lane and register, placed for a ds_swizzle broadcast inside each half wave:
             // lane 32 h + 4 (r & 7) + g holds y[pt(r, h)][g], r < 8 in yv0 and r >= 8 (the points 16 higher) in yv1
             float yv0 = 0.f, yv1 = 0.f;
-            if (FIRST) {
+            float yvp[3] = {0.f, 0.f, 0.f};                    // PAIR form: see first_dw_step_pair (`slab` is this lane group's slab)
+            if (FIRST && !PAIR) {
                 const int r7 = (lane >> 2) & 7, ypt = (r7 & 3) + 8 * (r7 >> 2) + 4 * h;
                 const float* yt = DZ0 + (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * Y_STRIDE + ypt * Y_STRIDE + (lane & 3);
                 if ((ypt >> 2) < rows_left) yv0 = yt[0];
                 if ((ypt >> 2) + 4 < rows_left) yv1 = yt[16 * Y_STRIDE];
+            }
+            if (FIRST && PAIR) {
+                const float* yt = DZ0 + (((size_t)slab * n_rows + m.row0 + wave * 8) * BK_NS) * Y_STRIDE;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int idx = 16 * q + (lane & 15), r = idx / 3, g = idx - 3 * r;
+                    const int ypt = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if ((ypt >> 2) < rows_left && lane_live) yvp[q] = yt[ypt * Y_STRIDE + g];
+                }
             }
             constexpr int GSEQ[3] = {1, 2, 0};                           // segment order
             bf16x8 wn[3];
@@ -1962,8 +1989,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                     STAMP_ADD(3);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] *= act_grad_from_output(ACT, a[r]);   // dX = acc * act'(aux)
-                    if (FIRST)                                           // dW_first[g][c = p] += y[pt(r, h)][g] * dx[pt(r, h)][p]
+                    if (FIRST && !PAIR)                                  // dW_first[g][c = p] += y[pt(r, h)][g] * dx[pt(r, h)][p]
                         first_dw_tile(std::make_integer_sequence<int, 16>{}, yv0, yv1, acc, dwf);
+                    if (FIRST && PAIR) first_dw_tile_pair(std::make_integer_sequence<int, 16>{}, yvp, acc, dwf);
                 }
                 // dW_g += aux^T T_g
 #pragma unroll
@@ -2020,16 +2048,17 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bwd_c32_bf16_kernel(PlanDev P, 
                 s += red[w * 3072 + ca * 96 + g * 32 + cc] + red[w * 3072 + (16 + ca) * 96 + g * 32 + 16 + cc];
             outp[i] = s;
         }
-        return;
-    }
-    float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
-    for (int i = threadIdx.x; i < 3072; i += BK_THREADS) {
-        float s = 0.f;
+    } else {
+        float* outp = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3072;
+        for (int i = threadIdx.x; i < 3072; i += BK_THREADS) {
+            float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < BK_WAVES; ++w) s += red[w * 3072 + i];
-        outp[i] = s;
+            for (int w = 0; w < BK_WAVES; ++w) s += red[w * 3072 + i];
+            outp[i] = s;
+        }
     }
     if (FIRST) {                                               // dW_first partial of this workgroup: [g][c], fixed order over (wave, h)
+                                                               // (PAIR: c = 16 s + channel, the two slabs are folded by the reduce kernel)
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 3; ++g) red[(wave * 2 + h) * 96 + g * 32 + p] = dwf[g];
@@ -2739,47 +2768,78 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
 
 // Backward of the layer that follows the first one, fused with the first layer's weight gradient (bwd_c32_bf16_kernel<.., FIRST>).
 // Workspace: [this layer's dW partials][dW_first partials: 96 floats per workgroup].
-bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch) { return scone_shape(c) && ns == BK_NS && ch == 32; }
+bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch) {
+    return scone_shape(c) && ns == BK_NS && (ch == 32 || ch == 16);          // 16: the slab-pair form
+}
 
 size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch) {
     if (!blocked_backward_first_supported(c, ns, ch)) return 0;
     dim3 grid;
-    launch_grid(c, n_slabs, bwd_lds(32, 32), grid);
-    return (size_t)grid.x * grid.y * (3072 + 96) * sizeof(float);
+    launch_grid(c, n_slabs, bwd_lds(ch, ch), grid);
+    return (size_t)grid.x * grid.y * (3 * ch * ch + 96) * sizeof(float);
 }
 
-int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
+// dW_first[slot][cc] of the slab-pair form: partial [b][slot * 32 + 16 s + cc], the two slabs s folded here (fixed order)
+__global__ __launch_bounds__(64) void dw_first_reduce_pair_kernel(const float* __restrict__ partial, int n_partials,
+                                                                  float* __restrict__ dW0, float* __restrict__ dW1,
+                                                                  float* __restrict__ dW2) {
+    const int o = blockIdx.x, lane = threadIdx.x;                 // o = slot * 16 + cc
+    const int slot = o >> 4, cc = o & 15;
+    float s = 0.f;
+    for (int b = lane; b < n_partials; b += 64) s += partial[(size_t)b * 96 + slot * 32 + cc] + partial[(size_t)b * 96 + slot * 32 + 16 + cc];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) {
+        float* d = slot == 0 ? dW0 : (slot == 1 ? dW1 : dW2);
+        d[cc] += s;
+    }
+}
+
+int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int ch, int act,
                            const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
                            hipStream_t st) {
     PlanDev P = c->plan.dev;
     const WorkList wl = wlp ? *wlp : WorkList{0, nullptr, nullptr, nullptr};
     dim3 grid;
-    const size_t lds = bwd_lds(32, 32);
+    const size_t lds = bwd_lds(ch, ch);
     launch_grid(c, n_slabs, lds, grid);
     P.assign = balanced_assignment(c, grid.x);
     if (wl.block) grid.y = 1;
     const int nr = c->n_rows, nc = c->g[0].n_cols;
     const int n_wg = (int)(grid.x * grid.y);
     float* partial = (float*)ws;
-    float* partial_first = partial + (size_t)n_wg * 3072;
-#define SCN_LAUNCH_BWDF(A)                                                                                        \
+    float* partial_first = partial + (size_t)n_wg * 3 * ch * ch;
+#define SCN_LAUNCH_BWDF(A, PAIRV)                                                                                 \
     do {                                                                                                          \
-        SCN_ENSURE_LDS((bwd_c32_bf16_kernel<A, false, false, true>), lds);                                        \
-        hipLaunchKernelGGL((bwd_c32_bf16_kernel<A, false, false, true>), grid, dim3(BK_THREADS), lds, st, P, dz, y, W[0], \
+        SCN_ENSURE_LDS((bwd_c32_bf16_kernel<A, false, PAIRV, true>), lds);                                        \
+        hipLaunchKernelGGL((bwd_c32_bf16_kernel<A, false, PAIRV, true>), grid, dim3(BK_THREADS), lds, st, P, dz, y, W[0], \
                            W[1], W[2], aux, (float*)nullptr, partial, nr, nc, n_slabs, wl, partial_first);        \
     } while (0)
-    switch (act) {
-        case SCN_ACT_TANH: SCN_LAUNCH_BWDF(SCN_ACT_TANH); break;
-        case SCN_ACT_RELU: SCN_LAUNCH_BWDF(SCN_ACT_RELU); break;
-        case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWDF(SCN_ACT_LEAKY_RELU); break;
-        default: SCN_LAUNCH_BWDF(SCN_ACT_NONE); break;
+    if (ch == 32) {
+        switch (act) {
+            case SCN_ACT_TANH: SCN_LAUNCH_BWDF(SCN_ACT_TANH, false); break;
+            case SCN_ACT_RELU: SCN_LAUNCH_BWDF(SCN_ACT_RELU, false); break;
+            case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWDF(SCN_ACT_LEAKY_RELU, false); break;
+            default: SCN_LAUNCH_BWDF(SCN_ACT_NONE, false); break;
+        }
+    } else {
+        switch (act) {
+            case SCN_ACT_TANH: SCN_LAUNCH_BWDF(SCN_ACT_TANH, true); break;
+            case SCN_ACT_RELU: SCN_LAUNCH_BWDF(SCN_ACT_RELU, true); break;
+            case SCN_ACT_LEAKY_RELU: SCN_LAUNCH_BWDF(SCN_ACT_LEAKY_RELU, true); break;
+            default: SCN_LAUNCH_BWDF(SCN_ACT_NONE, true); break;
+        }
     }
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(blocked_dw_reduce, dim3((32 * 3 * 32 + 255) / 256), dim3(256), 0, st, partial, n_wg, 32, 32, dW[0], dW[1],
+    hipLaunchKernelGGL(blocked_dw_reduce, dim3((ch * 3 * ch + 255) / 256), dim3(256), 0, st, partial, n_wg, ch, ch, dW[0], dW[1],
                        dW[2]);
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(96), dim3(64), 0, st, partial_first, n_wg, 32, dW_first[0], dW_first[1],
-                       dW_first[2]);
+    if (ch == 32)
+        hipLaunchKernelGGL(dw_first_reduce_kernel, dim3(96), dim3(64), 0, st, partial_first, n_wg, 32, dW_first[0], dW_first[1],
+                           dW_first[2]);
+    else
+        hipLaunchKernelGGL(dw_first_reduce_pair_kernel, dim3(48), dim3(64), 0, st, partial_first, n_wg, dW_first[0], dW_first[1],
+                           dW_first[2]);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -35,7 +35,7 @@ int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const fl
                            const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st);
 bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch);
 size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
-int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int act,
+int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int ch, int act,
                            const float* y, float* const* dW, float* const* dW_first, void* ws, const WorkList* wlp,
                            hipStream_t st);
 int build_terms_plan(scn_conv_s* c, const uint8_t* term, const int32_t* lvl_row0, const uint8_t* merged, const int32_t* bins,
@@ -572,7 +572,7 @@ int scn_conv_backward_fused_first(scn_conv_t c, int32_t n_slabs, int32_t ns, con
     if (workspace_bytes < blocked_backward_first_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
     WorkList wlist{0, nullptr, nullptr, nullptr};
     if (wl) wlist = to_list(wl);
-    return blocked_backward_first(c, n_slabs, dz, W, aux, act, y, dW, dW_first, workspace, wl ? &wlist : nullptr,
+    return blocked_backward_first(c, n_slabs, dz, W, aux, channels, act, y, dW, dW_first, workspace, wl ? &wlist : nullptr,
                                   (hipStream_t)stream);
 }
 

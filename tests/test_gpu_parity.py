@@ -737,8 +737,9 @@ def test_train_loop_with_empty_batches(cfg1, sc1):
     assert abs(res[2] - so.loss_from_preds(out, y, test_mask, adam.x, 5e-5)) <= 1e-5
 
 
+@pytest.mark.parametrize("hidden", [32, 16])             # 16: the slab-pair form of the kernels
 @pytest.mark.parametrize("mode", ["dense", "zeros"])
-def test_fused_first_layer_gradient_equals_the_separate_kernels(mode):
+def test_fused_first_layer_gradient_equals_the_separate_kernels(mode, hidden):
     """scn_conv_backward_fused_first (layer 1's backward contracts its input gradient with the shifted input y in registers and
     never writes it) against scn_conv_backward + scn_conv_dw_first on the same step: loss and all ten weight gradients."""
     _need_gpu()
@@ -762,7 +763,7 @@ def test_fused_first_layer_gradient_equals_the_separate_kernels(mode):
             ops.FUSE_FIRST = fused
             stm.reseed(1030)
             net = stm.Scone_GCN(1, 1e-3, N, 0.0, verbose=False, skip_mode=mode)
-            net.setup(te.scone_func, [(3, 32)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+            net.setup(te.scone_func, [(3, hidden)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
             with torch.no_grad():
                 for w in net.weights:
                     w.mul_(15.0)
