@@ -332,9 +332,10 @@ struct DenseBwdG1Args {
     float* dx;
     float* partial;
 };
+template <int CG, int ACT>                                        // CG = c_aux / 4 in {4, 8, 16}: 256 % CG == 0
 __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
     __shared__ f32x4 red[DN_MAX_TERMS * 256];
-    const int cg = a.c_aux / 4;                                     // 256 % cg == 0 (c_aux in {16, 32, 64})
+    constexpr int cg = CG;
     const int cq = threadIdx.x % cg;
     f32x4 w[DN_MAX_TERMS], acc[DN_MAX_TERMS];
 #pragma unroll
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
             }
         if (a.dx) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(a.act, x[j]);
-            __builtin_nontemporal_store(v, (f32x4*)(a.dx + i * 4));
+            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(ACT, x[j]);
+            __builtin_nontemporal_store(v, (f32x4*)(a.dx + i * 4));       // (a plain store: +5 %)
         }
     }
 #pragma unroll
@@ -497,7 +498,14 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
         g.partial = (float*)workspace;
         for (int k = 0; k < n_terms; ++k) { g.G[k] = G[k]; g.W[k] = W[k]; }
         const int nbs = (int)std::min<int64_t>(1024, (n_points * (c_aux / 4) + 255) / 256);
-        hipLaunchKernelGGL(dense_bwd_g1_kernel, dim3(nbs), dim3(256), 0, st, g);
+#define SCN_LAUNCH_G1(CG)                                                                                         \
+    switch (act) {                                                                                                \
+        case SCN_ACT_TANH: hipLaunchKernelGGL((dense_bwd_g1_kernel<CG, SCN_ACT_TANH>), dim3(nbs), dim3(256), 0, st, g); break; \
+        case SCN_ACT_RELU: hipLaunchKernelGGL((dense_bwd_g1_kernel<CG, SCN_ACT_RELU>), dim3(nbs), dim3(256), 0, st, g); break; \
+        case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL((dense_bwd_g1_kernel<CG, SCN_ACT_LEAKY_RELU>), dim3(nbs), dim3(256), 0, st, g); break; \
+        default: hipLaunchKernelGGL((dense_bwd_g1_kernel<CG, SCN_ACT_NONE>), dim3(nbs), dim3(256), 0, st, g); break; \
+    }
+        if (c_aux == 16) { SCN_LAUNCH_G1(4) } else if (c_aux == 32) { SCN_LAUNCH_G1(8) } else { SCN_LAUNCH_G1(16) }
         SCN_LAUNCH_CHECK();
         r.partial = g.partial; r.n_partials = nbs; r.total = r.off[n_terms]; r.n_terms = n_terms;
         hipLaunchKernelGGL(dense_dw_reduce, dim3((r.total + 255) / 256), dim3(256), 0, st, r);
