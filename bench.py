@@ -291,6 +291,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from scone_gcn_amd import distributed as dp
     from scone_gcn_amd import ops
     from scone_gcn_amd import synthetic_data_gen as g
     from scone_gcn_amd.complex import SimplicialComplex
@@ -302,11 +303,7 @@ def main():
         torch.cuda.synchronize()
 
     def all_max(dt):
-        if world > 1:
-            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-        return dt
+        return dp.all_max(dt, device="cuda" if args.backend == "nccl" else "cpu")
 
     weak = args.per_gpu_batch > 0
     if not weak and args.global_batch % world:

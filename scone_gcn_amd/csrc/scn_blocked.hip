@@ -678,16 +678,27 @@ __global__ __launch_bounds__(SP_THREADS, 4) void spmm_ring_kernel(PlanDev P, con
                                                  (__attribute__((address_space(3))) void*)(dst + ((i * (SP_THREADS / 64) + wave) * 64) * 16),
                                                  16, 0, 0);
         };
-        if (has_src)
+        // SCN_SPMM_FLOOR (diagnostic builds only, tools/spmm_ceiling.sh; results are WRONG by design): 1 = LDS-DMA + stores, no
+        // gather (what the memory system alone takes); 2 = gather + stores on whatever LDS holds, no LDS-DMA
+#if defined(SCN_SPMM_FLOOR) && SCN_SPMM_FLOOR == 2
+        const bool do_dma = false;
+#else
+        const bool do_dma = has_src;
+#endif
+        if (do_dma)
             for (int q = 0; q < 3 && q < n_stage; ++q) issue(q);
         // this thread's item of every stage: (row r, 16-byte chunk ch of the half piece)
         const int idx = threadIdx.x, r = idx / CPH, ch = idx - r * CPH;
         const bool live = r < m.rows;
+#if defined(SCN_SPMM_FLOOR) && SCN_SPMM_FLOOR == 1
+        const int tw = 0;
+#else
         const int tw = live ? __builtin_amdgcn_readfirstlane(tws[min(r, BK_R - 1) >> 3]) : 0;   // CPH >= 8: a wave's lanes share a row group
+#endif
         const int rb = r * m.w;
         for (int q = 0; q < n_stage; ++q) {
             wait_ring<NI>(min(n_stage - 1 - q, 2));
-            if (has_src && q + 3 < n_stage) issue(q + 3);
+            if (do_dma && q + 3 < n_stage) issue(q + 3);
             if (pend_a) {                                           // non-temporal, one stage late (see spmm_blocked_kernel)
                 __builtin_nontemporal_store(pa, (f32x4*)pend_a);
                 if (DUAL) __builtin_nontemporal_store(pb, (f32x4*)pend_b);

@@ -26,9 +26,10 @@ def shard_indices(idx, rank, world_size):
     return idx[bounds[rank]:bounds[rank + 1]]
 
 
-def all_reduce_sum_(flat, group=None):
-    """In-place sum of the flat gradient buffer over ranks (no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def all_reduce_sum_(flat, group=None, force=False):
+    """In-place sum of the flat gradient buffer over ranks (no-op for a single process, unless `force`: a one-rank
+    process group still runs the backend's collective -- the RCCL smoke test uses that on a one-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         if flat.is_cuda and dist.get_backend(group) == "gloo":
             # rehearsal on a box without RCCL peers: gloo reduces a host copy (tiny: the flat gradient buffer)
             host = flat.detach().cpu()
@@ -39,7 +40,7 @@ def all_reduce_sum_(flat, group=None):
     return flat
 
 
-def data_parallel_grad(idx, grad_fn, flat_grad, group=None):
+def data_parallel_grad(idx, grad_fn, flat_grad, group=None, force=False):
     """Generic DP step: `grad_fn(local_idx, total_count)` must ACCUMULATE into `flat_grad` the gradient of
     -sum_{n in local_idx} <logp_n, y_n> / total_count; afterwards flat_grad holds the full-batch gradient of the
     data term on every rank.  Returns the local index slice (for callers that also want the local loss)."""
@@ -48,7 +49,7 @@ def data_parallel_grad(idx, grad_fn, flat_grad, group=None):
     flat_grad.zero_()
     if len(local):
         grad_fn(local, len(idx))
-    all_reduce_sum_(flat_grad, group)
+    all_reduce_sum_(flat_grad, group, force)
     return local
 
 
@@ -56,3 +57,15 @@ def all_reduce_scalar(value, device, group=None):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     all_reduce_sum_(t, group)
     return float(t.item())
+
+
+def all_max(value, device=None, group=None, force=False):
+    """Maximum of a host scalar over ranks (bench.py: the step time every rank reports is the slowest rank's).  The
+    reduction runs on `device` (a CUDA device under RCCL, the host under gloo)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+        if device is None:
+            device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return float(t.item())
+    return float(value)

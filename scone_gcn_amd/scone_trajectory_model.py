@@ -66,6 +66,7 @@ class Scone_GCN():
         self.weight_decay = weight_decay
         self.verbose = verbose
         self.process_group = process_group
+        self.collective_always = False                 # True: run the gradient all-reduce even in a one-rank process group
         self.model_type = 'scone'
         self._flat_w = self._flat_g = self._m = self._v = None
         self._step = 0
@@ -248,7 +249,7 @@ class Scone_GCN():
         plan = self._plan(inputs)
         self._flat_g.zero_()
         loss = self._accumulate_staged(plan, staged, total)
-        dp.all_reduce_sum_(self._flat_g, self.process_group)
+        dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
         if apply:
             self._adam()
         return loss
@@ -265,7 +266,7 @@ class Scone_GCN():
 
         def grad_fn(local, total):
             acc["loss"] = self._accumulate_grad(plan, inputs, y, local, total)
-        dp.data_parallel_grad(idx, grad_fn, self._flat_g, self.process_group)
+        dp.data_parallel_grad(idx, grad_fn, self._flat_g, self.process_group, force=self.collective_always)
         if apply:
             self._adam()
         return acc.get("loss", torch.zeros((), device=self._flat_w.device, dtype=torch.float64))
@@ -281,7 +282,7 @@ class Scone_GCN():
         self._flat_g.zero_()
         for g, v in zip(gs, self._grads):
             v.add_(g)
-        dp.all_reduce_sum_(self._flat_g, self.process_group)
+        dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
         if apply:
             self._adam()
         return data.detach().double()

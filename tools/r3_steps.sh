@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage: tools/r3_steps.sh <outdir> <step> [<step> ...]   -- GPU-box driver: runs the named measurement steps one after another,
+# each under its own timeout, logs under <outdir>; stops at the first step that had to be killed.
+OUT=$1; shift
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+step() {
+  local name=$1 limit=$2; shift 2
+  local t0=$(date +%s)
+  timeout -k 10 $limit "$@" > $OUT/$name.log 2>&1
+  local rc=$?
+  echo "$name rc=$rc $(( $(date +%s) - t0 ))s" | tee -a $OUT/status.txt
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed at its limit: stopping" | tee -a $OUT/status.txt; exit 1; fi
+}
+for s in "$@"; do
+  case $s in
+    tests_dense) step tests_dense 700 python3 -m pytest tests/test_gpu_fullsize_dense.py tests/test_gpu_rccl.py -x -q -m gpu ;;
+    tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
+    pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
+    pmc_c32)     step pmc_c32 400 bash tools/pmc_run.sh $OUT/pmc_c32 sq1,sq2,sq4 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
+    pmc_c32_mem) step pmc_c32_mem 400 bash tools/pmc_run.sh $OUT/pmc_c32_mem fetch,write,tcc tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 2 ;;
+    spmm_ceiling) step spmm_ceiling 600 bash tools/spmm_ceiling.sh $OUT/spmm ;;
+    bench)       step bench 900 python3 bench.py ;;
+    bench_quick) step bench_quick 400 python3 bench.py --extras 0 --steps 5 --warmup 1 ;;
+    prof_kernels) step prof_kernels 300 python3 tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 3 ;;
+    bunch_scale) step bunch_scale 300 python3 tools/model_scale.py bunch 1000000 64 32 ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
+cat $OUT/status.txt
