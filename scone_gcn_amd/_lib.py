@@ -112,7 +112,7 @@ _lib = None
 
 
 class SconeHipError(RuntimeError):
-    pass
+    status = 0                        # the C-ABI status code (include/scone_hip.h)
 
 
 def load():
@@ -141,7 +141,9 @@ def check(status, what):
         lib = load()
         msg = lib.scn_error_string(status).decode()
         hip = lib.scn_last_hip_error().decode()
-        raise SconeHipError(f"{what} failed: {msg} (status {status})" + (f" [{hip}]" if status == -3 and hip else ""))
+        err = SconeHipError(f"{what} failed: {msg} (status {status})" + (f" [{hip}]" if status == -3 and hip else ""))
+        err.status = status
+        raise err
 
 
 def ptr_array(ptrs):

@@ -10,7 +10,7 @@ mkdir -p "$HERE/build"
 pids=()
 for f in scn_conv scn_blocked scn_readout scn_dense; do
   src="$HERE/$f.hip"; obj="$HERE/build/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/scn_internal.h" -nt "$obj" ] || [ "$HERE/scn_terms.inc" -nt "$obj" ] || [ "$ROOT/include/scone_hip.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/scn_internal.h" -nt "$obj" ] || [ -n "$(find "$HERE" -name "*.inc" -newer "$obj")" ] || [ "$ROOT/include/scone_hip.h" -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

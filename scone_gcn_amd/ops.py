@@ -4,7 +4,6 @@ ConvOp wraps a scn_conv_t; SconePlan / BunchPlan hold everything one model needs
 expose forward / backward over "flow slabs" ([n_slabs, rows, ns, C] fp32, see include/scone_hip.h).
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -74,8 +73,9 @@ def _nbytes(*tensors):
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
-FUSE_FIRST = os.environ.get("SCN_NO_FUSED_FIRST") is None      # A/B switch: separate scn_conv_backward + scn_conv_dw_first
-FUSE_BUNCH = os.environ.get("SCN_NO_FUSED_BUNCH") is None      # A/B switch: per-shift SpMMs + dense-term kernels for every Bunch layer
+# Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
+FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
+FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
 
 
 def _stream():
@@ -294,6 +294,11 @@ class ConvOp:
         check(_lib.load().scn_conv_plan_blocks(self.handle, row0.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
               "scn_conv_plan_blocks")
         return row0
+
+    def dw_first_served(self, dz):
+        """Whether dw_first takes this gradient tensor's shape (scn_conv_dw_first_workspace > 0)."""
+        S, rows, ns, c = dz.shape
+        return rows == self.n_rows and int(_lib.load().scn_conv_dw_first_workspace(self.handle, S, ns, c)) > 0
 
     def dw_first(self, x, y, dz, dWs, wl=None):
         """First-layer weight gradient through the forward operator (scn_conv_dw_first); y: the shifted input saved by
@@ -544,6 +549,40 @@ def _last_nodes_dev(last_nodes, n_pad, device):
 
 
 # ----------------------------------------------------------------------------------------------
+# hidden-width promotion
+# ----------------------------------------------------------------------------------------------
+# The MFMA kernels serve hidden widths 16 (on slab pairs) and 32.  Any other stack the reference documents -- mixed widths such
+# as `-hidden_layers [(3, 32), (3, 16)]` (TE:51) or 3_8_3_8 (TE:82) -- runs on the SAME kernels with every hidden width
+# zero-padded to one promoted width: no layer of this path has a bias and act(0) = 0 for every activation it uses, so the padded
+# channels are exactly zero in every activation and every gradient, the real channels see the same sums (the extra terms
+# are exact zeros), and the padded rows / columns of the weight gradients are dropped again on the way out.
+
+def promoted_width(widths):
+    """Width every hidden layer is padded to, or None when the stack runs as it is (uniform 16 or 32, or wider than 32)."""
+    ws = {int(c) for c in widths}
+    if len(ws) == 1 and ws <= {16, 32}:
+        return None
+    m = max(ws)
+    return 16 if m <= 16 else (32 if m <= 32 else None)
+
+
+def promote_weights(weights, n_first, n_last, P):
+    """Zero-padded copies: rows of every matrix but the first layer's n_first, columns of every matrix but the last n_last."""
+    out, n = [], len(weights)
+    for i, w in enumerate(weights):
+        r = w.shape[0] if i < n_first else P
+        c = w.shape[1] if i >= n - n_last else P
+        out.append(w if (r, c) == tuple(w.shape) else torch.nn.functional.pad(w, (0, c - w.shape[1], 0, r - w.shape[0])).contiguous())
+    return out
+
+
+def demote_grads(grads, padded):
+    for g, gp in zip(grads, padded):
+        if gp is not g:
+            g.add_(gp[:g.shape[0], :g.shape[1]])
+
+
+# ----------------------------------------------------------------------------------------------
 # scone / ebli
 # ----------------------------------------------------------------------------------------------
 
@@ -728,7 +767,7 @@ class SconePlan:
 
     def release(self, saved):
         """Forward-only use of the zero-skipping mode (prediction): hand the forward's pooled buffers back, all-zero again."""
-        hs, bh, y0, activity = saved
+        hs, bh, y0, activity, _ = saved
         if activity:
             for l in range(1, len(hs)):
                 self._give_back(hs[l], activity["fwd"][l - 1])
@@ -752,10 +791,23 @@ class SconePlan:
                                       _dev(logp), _stream()), "scn_readout_forward")
         return logp, bh, logits
 
+    def _blocked(self):
+        op = self.conv if self.conv is not None else self.op
+        return op.plan_info()[0] > 0
+
+    def promotion(self, weights):
+        """Promoted hidden width of this weight list on this plan (None: runs as it is)."""
+        if len(weights) < 4 or (len(weights) - 1) % 3 or not self._blocked():
+            return None
+        return promoted_width([w.shape[1] for w in weights[:-1]])
+
     def forward(self, x, last_dev, weights, activity=None):
-        hs, y0 = self.conv_stack(x, weights, activity)
-        logp, bh, _ = self.readout(hs[-1], weights[-1], last_dev)
-        return logp, (hs, bh, y0, activity)
+        P = self.promotion(weights)
+        wp = promote_weights(weights, 3, 1, P) if P else None
+        w = wp if P else weights
+        hs, y0 = self.conv_stack(x, w, activity)
+        logp, bh, _ = self.readout(hs[-1], w[-1], last_dev)
+        return logp, (hs, bh, y0, activity, wp)
 
     def _readout_grad(self, H, bh, logp, d_logp, last_dev, weights, grads):
         """Gradient of the readout w.r.t. the last layer's pre-activation, into a pooled all-zero buffer (it is zero except
@@ -786,8 +838,16 @@ class SconePlan:
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         """grads: list of tensors (same shapes as weights) accumulated into."""
-        lib = _lib.load()
-        hs, bh, y0, activity = saved
+        wp = saved[4]
+        if wp is not None:                              # promoted widths: gradients of the padded matrices, cut back afterwards
+            gp = [torch.zeros_like(w) if w is not w0 else g for w, w0, g in zip(wp, weights, grads)]
+            self._backward(saved, logp, d_logp, last_dev, wp, gp)
+            demote_grads(grads, gp)
+            return grads
+        return self._backward(saved, logp, d_logp, last_dev, weights, grads)
+
+    def _backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        hs, bh, y0, activity, _ = saved
         dz_top, key = self._readout_grad(hs[-1], bh, logp, d_logp, last_dev, weights, grads)
         S, E, ns, C = hs[-1].shape
         L = len(hs) - 1
@@ -863,8 +923,8 @@ class PowerPlan(SconePlan):
             hs.append(out)
         return hs, y0
 
-    def backward(self, saved, logp, d_logp, last_dev, weights, grads):
-        hs, bh, y0, _ = saved
+    def _backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        hs, bh, y0, _, _ = saved
         dz_top, key = self._readout_grad(hs[-1], bh, logp, d_logp, last_dev, weights, grads)
         L = len(hs) - 1
         dz = dz_top
@@ -955,15 +1015,26 @@ class BunchPlan:
         return self._generic
 
     def _terms_ops(self):
-        """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer."""
+        """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer.
+        None when the plan builder cannot hold the complex (SCN_ERR_UNSUPPORTED: a single concatenated row with more than
+        104 distinct sources, e.g. a hub node) -- the per-shift path then carries every layer, forward AND backward."""
         if self._terms is None:
             dev = self._dev_csr
-            # bins: rows of (nodes, edges, faces) a block holds = the natural 0.37 : 1 : 0.67 proportions in wave units
-            fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)}, self.layout.merged, (12, 32, 20), 4)
-            bwd = TermsOp(self.sizes, {(BUNCH_SRC[k], BUNCH_DST[k]): dev[k].T.tocsr() for k in range(7)}, self.layout.merged,
-                          (16, 32, 16), 8)
-            self._terms = (fwd, bwd)
-        return self._terms
+            try:
+                # bins: rows of (nodes, edges, faces) a block holds = the natural 0.37 : 1 : 0.67 proportions in wave units
+                fwd = TermsOp(self.sizes, {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7)}, self.layout.merged,
+                              (12, 32, 20), 4)
+                bwd = TermsOp(self.sizes, {(BUNCH_SRC[k], BUNCH_DST[k]): dev[k].T.tocsr() for k in range(7)}, self.layout.merged,
+                              (16, 32, 16), 8)
+                self._terms = (fwd, bwd)
+            except _lib.SconeHipError as e:
+                if e.status != _lib.SCN_ERR_UNSUPPORTED:
+                    raise
+                self._terms = False
+        return self._terms or None
+
+    def _fused_ok(self, ns, widths_out, widths_in):
+        return (FUSE_BUNCH and ns == NS and set(widths_out) == {32} and set(widths_in) == {32} and self._terms_ops() is not None)
 
     @staticmethod
     def _slot(dst, src):
@@ -1000,7 +1071,7 @@ class BunchPlan:
             nxt, nzero = [], []
             c_outs = {weights[7 * i + k].shape[1] for k in range(7)}
             c_ins = {cur[l].shape[3] for l in range(3) if not zero[l] and cur[l] is not None}
-            if FUSE_BUNCH and ns == NS and c_outs == {32} and c_ins == {32}:
+            if self._fused_ok(ns, c_outs, c_ins):
                 # fused layer: one launch for the three levels (scn_terms_forward)
                 xs = [None if (zero[l] or cur[l] is None) else cur[l] for l in range(3)]
                 Ws = [[None] * 3 for _ in range(3)]
@@ -1052,9 +1123,16 @@ class BunchPlan:
         self._first_g = first_g
         return states
 
+    def promotion(self, weights):
+        if len(weights) < 14 or len(weights) % 7:
+            return None
+        return promoted_width([w.shape[1] for w in weights[:-7]])
+
     def forward(self, x, last_dev, weights):
         lib = _lib.load()
-        states = self.conv_stack(x, weights)
+        P = self.promotion(weights)
+        wp = promote_weights(weights, 7, 7, P) if P else None
+        states = self.conv_stack(x, wp if P else weights)
         nodes_out = states[-1][0]
         S, V, ns, C = nodes_out.shape
         assert C == 1, "bunch readout needs one output channel (TE:198-201)"
@@ -1063,11 +1141,20 @@ class BunchPlan:
         check(lib.scn_node_readout_forward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
                                            _dev(last_dev, torch.int32), _dev(logits), _dev(logp), _stream()),
               "scn_node_readout_forward")
-        return logp, (states, self._zeros, self._first_g)
+        return logp, (states, self._zeros, self._first_g, wp)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
+        wp = saved[3]
+        if wp is not None:                              # promoted widths (see promote_weights)
+            gp = [torch.zeros_like(w) if w is not w0 else g for w, w0, g in zip(wp, weights, grads)]
+            self._backward(saved, logp, d_logp, last_dev, wp, gp)
+            demote_grads(grads, gp)
+            return grads
+        return self._backward(saved, logp, d_logp, last_dev, weights, grads)
+
+    def _backward(self, saved, logp, d_logp, last_dev, weights, grads):
         lib = _lib.load()
-        states, zeros, first_g = saved
+        states, zeros, first_g, _ = saved
         nodes_out = states[-1][0]
         S, V, ns, _ = nodes_out.shape
         dz = [torch.empty_like(nodes_out), None, None]
@@ -1081,7 +1168,7 @@ class BunchPlan:
             new_dz, new_zero = [None, None, None], [True, True, True]
             c_dz = {dz[l].shape[3] for l in range(3) if not dzero[l]}
             c_x = {x[l].shape[3] for l in range(3) if not xzero[l] and x[l] is not None}
-            if FUSE_BUNCH and ns == NS and c_dz == {32} and c_x == {32}:
+            if self._fused_ok(ns, c_dz, c_x):
                 # fused layer backward on the transposed operator (scn_terms_backward): rows = this layer's input rows
                 dzs = [None if dzero[l] else dz[l] for l in range(3)]
                 auxs = [None if (xzero[l] or x[l] is None) else x[l] for l in range(3)]
@@ -1107,18 +1194,17 @@ class BunchPlan:
             if i == 0 and FUSE_BUNCH and first_g and all(x[l] is None or x[l].shape[3] == 1 for l in range(3)):
                 # first layer (one 1-channel input level): the shift sits on the 1-channel side, dW_k[0][c] = sum_p (S_k x)[p] dz[p][c]
                 # -- dz of every level streamed once, no transposed SpMM, no gathered 32-channel tensor (scn_conv_dw_first)
-                done = True
-                for k, g in first_g.items():
-                    d = dz[BUNCH_DST[k]]
-                    if dzero[BUNCH_DST[k]] or d is None:
-                        continue
-                    y = torch.zeros((g.shape[0], g.shape[1], g.shape[2], Y_STRIDE), device=g.device, dtype=torch.float32)
-                    y[..., 0] = g[..., 0]
-                    dummy = [torch.zeros_like(grads[k]) for _ in range(2)]
-                    done = done and self.term_fwd[k].dw_first(None, y, d, [grads[k]] + dummy)
-                    if not done:
-                        break
-                if done:
+                live = [(k, g, dz[BUNCH_DST[k]]) for k, g in first_g.items()
+                        if not dzero[BUNCH_DST[k]] and dz[BUNCH_DST[k]] is not None]
+                # all or nothing: the per-level loop below accumulates EVERY shift's gradient, so this path may only touch
+                # `grads` when it serves all of them (every shift's operator builds its block plan on its own)
+                if all(self.term_fwd[k].dw_first_served(d) for k, _, d in live):
+                    for k, g, d in live:
+                        y = torch.zeros((g.shape[0], g.shape[1], g.shape[2], Y_STRIDE), device=g.device, dtype=torch.float32)
+                        y[..., 0] = g[..., 0]
+                        dummy = [torch.zeros_like(grads[k]) for _ in range(2)]
+                        served = self.term_fwd[k].dw_first(None, y, d, [grads[k]] + dummy)
+                        assert served
                     break
             for lvl in range(3):
                 ks = [k for k in self.bwd_slots[lvl] if not dzero[BUNCH_DST[k]]]

@@ -209,6 +209,9 @@ class Scone_GCN():
         device = self._flat_w.device
         k = 7 if self.model_type == 'bunch' else 3
         widths = [1] + [self._shapes[k * i][1] for i in range(len(self._shapes) // k)]
+        P = plan.promotion(self.weights)                # hidden widths the kernels do not take are zero-padded (ops.promote_weights)
+        if P:
+            widths = [w if w == 1 else P for w in widths]
         rows = sum(plan.sizes) if self.model_type == 'bunch' else plan.n_edges
         mb = ops.micro_batch_size(rows, widths, len(idx), device=device)
         staged = []

@@ -105,3 +105,43 @@ def test_bunch_matches_the_csr_oracle_and_scales_at_one_million_edges(big_comple
     o2 = te.bunch_func(net.weights, *shifts, nbrhoods, last, f2).cpu().numpy().astype(np.float64)[:, :, 0]
     d1, d2 = o1 - o1[:, :1], o2 - o2[:, :1]
     assert np.abs(d2 - a * d1).max() <= 2e-5 * max(1.0, np.abs(d2).max())
+
+
+@pytest.mark.parametrize("layers", [[(3, 32), (3, 16)], [(3, 16), (3, 32)]])
+def test_mixed_width_stacks_at_one_million_edges(big_complex, layers):
+    """TE:51's `[(3, 32), (3, 16)]` (and its mirror) on the benchmark complex: loss and all seven weight gradients against the
+    fp64 CSR oracle, and the step time of the promoted stack within 2x of the uniform hidden-32 stack of the same depth."""
+    import time
+    from scone_gcn_amd import scone_trajectory_model as stm, synthetic_data_gen as g, trajectory_experiments as te
+    cx, sc = big_complex
+    N = 6
+    flows, last, y = _dataset(cx, sc, N, 41)
+    w = _weights(so.weight_shapes(1, layers, 1), 0.12, 9)
+    B1, B2 = g.incidence_matrices(cx)
+    L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+    B1x = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()
+    Bc = lambda n: B1x[sc.nbrhoods[n]].toarray()
+    ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, Bc, last, flows.todense().astype(np.float64), y, np.ones(N, int), 0.0)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    times = {}
+    for name, ls in (("mixed", layers), ("uniform32", [(3, 32), (3, 32)])):
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-3, N, 0.0, verbose=False)
+        net.setup(te.scone_func, ls, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+        if name == "mixed":
+            for a, b in zip(net.weights, w):
+                a.copy_(torch.as_tensor(b, dtype=torch.float32))
+        staged = net.stage(inputs, y, np.arange(N))
+        loss = float(net.grad_step_staged(inputs, staged, N, apply=False))
+        if name == "mixed":
+            grads = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+            _check(loss, grads, ref_loss, ref_g, "scone %s, |E| = %d" % (layers, cx.n_edges))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            net.grad_step_staged(inputs, staged, N, apply=False)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 3
+    print("step time mixed %.2f ms, uniform hidden 32 %.2f ms" % (times["mixed"] * 1e3, times["uniform32"] * 1e3))
+    assert times["mixed"] <= 2.0 * times["uniform32"]

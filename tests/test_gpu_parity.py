@@ -83,6 +83,58 @@ def test_forward_and_gradients_match_oracle(cfg1, sc1, model, hidden):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
 
 
+@pytest.mark.parametrize("model,layers", [("scone", [(3, 32), (3, 16)]), ("scone", [(3, 16), (3, 32)]),
+                                          ("ebli", [(3, 32), (3, 16)]), ("ebli", [(3, 16), (3, 32)]),
+                                          ("scone", [(3, 8), (3, 8)]), ("scone", [(3, 16), (3, 24), (3, 8)])])
+def test_reference_documented_layer_shapes_match_oracle(cfg1, sc1, model, layers):
+    """The stacks the reference's own documentation names -- `-hidden_layers [(3, 32), (3, 16)]` (TE:51), 3_8_3_8 (TE:82) -- and
+    other mixed widths: log-probabilities, loss and every weight gradient against the oracle.  They run on the MFMA kernels with
+    the hidden widths zero-padded to one promoted width (ops.promote_weights), never on the one-row-per-workgroup generic path."""
+    from scone_gcn_amd import ops, trajectory_experiments as te
+    sel = np.arange(40, 67)
+    shapes = so.weight_shapes(1, layers, 1)
+    w = _rand_weights(shapes, 0.25 if model == "scone" else 0.03, 11)
+    shifts_o, Bc, X, act = _oracle_scone(cfg1, w, sel, model)
+    y, last = cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    mask = np.ones(len(sel), int)
+    mask[[0, 20]] = 0
+    ref_out = so.scone_forward(w, shifts_o[0], shifts_o[1], Bc, last, X, act)
+    ref_loss, ref_g = so.scone_loss_and_grad(w, shifts_o[0], shifts_o[1], Bc, last, X, y, mask, 0.0, act)
+    shifts, readout, _ = te.setup_from_complex(sc1, model)
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    with ops.KernelTimer() as kt:
+        out = te.MODEL_FUNCS[model](wt, *shifts, readout, last, X)
+        m = torch.as_tensor(mask, device="cuda").bool()
+        yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
+        loss = -(out[m] * yt[m]).sum() / m.sum()
+        loss.backward()
+    P = ops.promoted_width([c for _, c in layers])
+    keys = list(kt.summary())
+    assert any(k == "conv_fwd c%d->%d" % (P, P) for k in keys), keys           # the uniform-width MFMA kernels carried it
+    assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert wt[k].grad.shape == wt[k].shape
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
+def test_mixed_width_bunch_matches_oracle(cfg1, sc1):
+    """Bunch with 7_32_7_16 hidden layers: promoted to 32 everywhere, so the fused three-level kernels carry the middle layer."""
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(200, 219)
+    w = _rand_weights(so.weight_shapes(1, [(7, 32), (7, 16)], 1, "bunch"), 0.4, 5)
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
+    ref_loss, ref_g = so.bunch_loss_and_grad(w, [s_.csr for s_ in shifts], nbrhoods, last, X, y, np.ones(len(sel), int), 0.0)
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+    loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / len(sel)
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
 def test_single_sample_call(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     shapes = so.weight_shapes(1, [(3, 16)] * 3, 1)
@@ -388,6 +440,114 @@ def test_spmm_blocks_without_sources():
         for s_ in range(5):
             assert _maxdiff(y[s_], m @ x[s_].astype(np.float64)) <= 2e-5
         assert not y[:, :192].any() and not y[:, 400:530].any()
+
+
+def test_bunch_on_a_complex_with_a_hub_node_falls_back_to_the_per_shift_path():
+    """A node of degree 110: its row of the concatenated Bunch operator has > 104 distinct sources, which the fused-layer plan
+    cannot hold (scn_terms_create -> SCN_ERR_UNSUPPORTED).  BunchPlan must then run every layer, forward AND backward, on the
+    per-shift SpMM + dense-term path (it used to raise at hidden 32): loss and all 28 weight gradients against the oracle."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    base = g.random_SC_graph(700)
+    hub = base.n_nodes
+    near = np.argsort(np.linalg.norm(base.coords - [0.5, 0.5], axis=1))[:110]
+    inset = np.zeros(hub + 1, bool)
+    inset[near] = True
+    spokes = np.stack([near, np.full(len(near), hub)], axis=1)
+    rim = base.edges[inset[base.edges[:, 0]] & inset[base.edges[:, 1]]]
+    cones = np.concatenate([rim, np.full((len(rim), 1), hub)], axis=1)            # (a, b, hub): sorted, hub is the largest id
+    cx = g.Complex(n_nodes=hub + 1, edges=np.unique(np.concatenate([base.edges, spokes]), axis=0),
+                   faces=np.unique(np.concatenate([base.faces, cones]), axis=0),
+                   coords=np.concatenate([base.coords, [[0.5, 0.5]]]))
+    sc = SimplicialComplex(cx)
+    assert int(np.bincount(cx.edges.ravel()).max()) == 110
+    paths = g.generate_random_walks(base, m=14, seed=5)                           # walks on the base complex (its edges all exist)
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=2)
+    n = len(paths)
+    X = flows.todense()[:n].astype(np.float64)
+    last = np.asarray(last[:n])
+    y = so.onehot_targets(choice[:n], sc.max_degree)
+    w = _rand_weights(so.weight_shapes(1, [(7, 32)] * 3, 1, "bunch"), 0.2, 5)
+    B1, B2 = g.incidence_matrices(cx)
+    S = [m.tocsr() for m in compute_shift_matrices(B1, B2)]
+    ref_loss, ref_g = so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, np.ones(n, int), 0.0)
+    shifts, nbrhoods, _ = te.setup_from_complex(sc, "bunch")
+    plan = ops.get_bunch_plan(shifts, nbrhoods, ops.default_device())
+    assert plan._terms_ops() is None                                              # the fused-layer plan refused the hub row
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    with ops.KernelTimer() as kt:
+        out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+        loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / n
+        loss.backward()
+    assert not any(k.startswith("terms_") for k in kt.summary())
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
+def test_fused_bunch_layer_with_an_absent_level_and_poisoned_lds():
+    """scn_terms_forward / _backward with level tensors that are not given (x[0] = None, dz[0] = None): the staging skips their
+    source rows, so the padded ELL entries of the PRESENT terms must not read those LDS pieces -- a preceding launch leaves
+    NaN bit patterns there (a dual SpMM over an all-NaN tensor fills both staging buffers of every CU)."""
+    _need_gpu()
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(2500)
+    sc = SimplicialComplex(cx)
+    shifts, nbr, _ = te.setup_from_complex(sc, "bunch")
+    plan = ops.get_bunch_plan(shifts, nbr, ops.default_device())
+    fwd, bwd = plan._terms_ops()
+    S, sizes = 2, plan.sizes
+    SRC, DST = ops.BUNCH_SRC, ops.BUNCH_DST
+    rs = np.random.RandomState(3)
+    dev = [s_.device_csr().astype(np.float64) for s_ in shifts]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def poison():
+        nan = torch.full((4, sizes[1], 128), float("nan"), device="cuda")
+        plan.term_fwd[3].spmm_dual(nan, dual=False)
+        torch.cuda.synchronize()
+
+    def shift(m, x):
+        y = m @ x.transpose(1, 0, 2, 3).reshape(x.shape[1], -1).astype(np.float64)
+        return y.reshape(m.shape[0], x.shape[0], 4, 32).transpose(1, 0, 2, 3)
+    xs = [None, rs.randn(S, sizes[1], 4, 32).astype(np.float32), rs.randn(S, sizes[2], 4, 32).astype(np.float32)]
+    Wk = [(0.2 * rs.randn(32, 32)).astype(np.float32) for _ in range(7)]
+    Ws = [[None] * 3 for _ in range(3)]
+    for k in range(7):
+        if xs[SRC[k]] is not None:
+            Ws[DST[k]][SRC[k]] = t(Wk[k])
+    poison()
+    outs = fwd.forward([None if x is None else t(x) for x in xs], Ws, "relu", [True] * 3)
+    for l in range(3):
+        ref = sum(shift(dev[k], xs[SRC[k]]) @ Wk[k].astype(np.float64) for k in range(7) if DST[k] == l and xs[SRC[k]] is not None)
+        got = outs[l].cpu().numpy()
+        assert np.isfinite(got).all()
+        assert _maxdiff(got, np.maximum(ref, 0)) <= 2e-5
+    dzs = [None, rs.randn(S, sizes[1], 4, 32).astype(np.float32), rs.randn(S, sizes[2], 4, 32).astype(np.float32)]
+    auxs = [np.maximum(rs.randn(S, n_, 4, 32), 0).astype(np.float32) for n_ in sizes]
+    Wb = [[None] * 3 for _ in range(3)]
+    dWb = [[None] * 3 for _ in range(3)]
+    for k in range(7):
+        if dzs[DST[k]] is not None:
+            Wb[SRC[k]][DST[k]], dWb[SRC[k]][DST[k]] = t(Wk[k]), torch.zeros((32, 32), device="cuda")
+    poison()
+    dxs = ops._terms_backward(bwd, [None if d is None else t(d) for d in dzs], Wb, [t(a) for a in auxs], "relu", [True] * 3, dWb)
+    for a in range(3):
+        gk = {k: shift(dev[k].T.tocsr(), dzs[DST[k]]) for k in range(7) if SRC[k] == a and dzs[DST[k]] is not None}
+        ref = sum(gk[k] @ Wk[k].astype(np.float64).T for k in gk) * (auxs[a] > 0)
+        got = dxs[a].cpu().numpy()
+        assert np.isfinite(got).all()
+        assert _maxdiff(got, ref) <= 2e-5
+        for k in gk:
+            refw = np.einsum("srnc,srnd->cd", auxs[a].astype(np.float64), gk[k])
+            assert _maxdiff(dWb[a][DST[k]].cpu().numpy(), refw) <= 2e-5 * max(1.0, np.abs(refw).max())
 
 
 def test_bunch_two_layers_larger_complex_against_csr_oracle():

@@ -329,3 +329,33 @@ def test_bench_refuses_a_rank_count_it_cannot_have():
     env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "2", "0", "0"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_hidden_width_promotion_pads_and_cuts_back():
+    """ops.promoted_width / promote_weights / demote_grads (host logic of the mixed-width path): which stacks are padded, to
+    what, and that padding a matrix and cutting its gradient back are inverse on the real entries."""
+    import torch
+    from scone_gcn_amd import ops
+    assert ops.promoted_width([16, 16, 16]) is None and ops.promoted_width([32, 32]) is None
+    assert ops.promoted_width([32, 16]) == 32 and ops.promoted_width([16, 32]) == 32
+    assert ops.promoted_width([8, 8]) == 16 and ops.promoted_width([16, 24, 8]) == 32
+    assert ops.promoted_width([40, 40]) is None and ops.promoted_width([32, 64]) is None
+    rs = np.random.RandomState(0)
+    shapes = [(1, 32)] * 3 + [(32, 16)] * 3 + [(16, 1)]
+    w = [torch.tensor(rs.randn(*s_), dtype=torch.float32) for s_ in shapes]
+    wp = ops.promote_weights(w, 3, 1, 32)
+    assert [tuple(t.shape) for t in wp] == [(1, 32)] * 3 + [(32, 32)] * 3 + [(32, 1)]
+    assert all(wp[i] is w[i] for i in range(3))                         # nothing to pad: the caller's tensor itself
+    for a, b in zip(w, wp):
+        assert torch.equal(b[:a.shape[0], :a.shape[1]], a)
+        assert int((b != 0).sum()) == int((a != 0).sum())               # the padding is exact zeros
+    # a padded stack computes the same function: dense check of one layer  act(X W) with zero-padded channels
+    X = torch.tensor(rs.randn(5, 32), dtype=torch.float32)
+    h = torch.tanh(X @ w[3])
+    hp = torch.tanh(X @ wp[3])
+    assert torch.equal(hp[:, :16], h) and float(hp[:, 16:].abs().max()) == 0.0
+    assert torch.allclose(hp @ wp[6], h @ w[6], atol=1e-6)
+    g = [torch.zeros_like(t) for t in w]
+    gp = [torch.full_like(t, 2.0) if t is not t0 else g0 for t, t0, g0 in zip(wp, w, g)]
+    ops.demote_grads(g, gp)
+    assert all(float(g[i].sum()) == 0.0 for i in range(3)) and all(bool((g[i] == 2.0).all()) for i in range(3, 7))
