@@ -125,7 +125,7 @@ int scn_spmm_dual(scn_conv_t conv, int32_t n_slabs, int32_t k,
  *   backward: dx[p,:] = ( sum_k G[k][p,:] @ W[k]^T ) * act'(aux[p,:]) ; dW[k] += sum_p aux[p,:]^T G[k][p,:]
  *             with G[k] = S_k^T dZ device [n_points][c[k]], W[k] device [c_aux][c[k]] (forward weights), aux = this
  *             level's forward input [n_points][c_aux]; dx may be NULL; deterministic reduction order.
- * n_points counts every (slab, row, trajectory) of the level; n_terms <= 3.                                        */
+ * n_points counts every (slab, row, trajectory) of the level; n_terms <= 3 (<= 6 when every term is one channel wide). */
 int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* const* G, const int32_t* c_in,
                             const float* const* W, int32_t c_out, int32_t act, float* out, void* stream);
 size_t scn_dense_terms_backward_workspace(int64_t n_points, int32_t n_terms, const int32_t* c, int32_t c_aux);
@@ -177,6 +177,20 @@ int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
                               const float* nodes_out, const int32_t* nbr, int32_t max_deg,
                               const int32_t* last_nodes, const float* d_logp, const float* logp,
                               int32_t act, float* dz, void* stream);
+
+/* The first two Bunch layers without a 32-channel gather (bunch_func, TE:179-195): the model starts from [0, flow, 0], so layer
+ * one's output of every level is relu of ONE rank-one term, H1_j[p][:] = relu(g_j[p] w_j) with g_j = S x one channel wide, and
+ *   relu(g w) = max(g, 0) relu(w) + min(g, 0) min(w, 0)      =>      (S_k H1_j) W_k = (S_k g_j^+) (relu(w_j) W_k) + (S_k g_j^-) (min(w_j, 0) W_k).
+ * scn_split_sign:     g_pos = max(g, 0), g_neg = min(g, 0) elementwise (n floats).
+ * scn_fold1_forward:  a_pos[c2] = relu(w1)[c1] @ W2[c1][c2],  a_neg = min(w1, 0) @ W2   -- the rank-one weights of layer two's
+ *                     expansion (scn_dense_terms_forward over the shifted scalars S_k g^+, S_k g^-).
+ * scn_fold1_backward: given u_pos[c2] = sum_p (S_k g^+)[p] dZ2[p][:] and u_neg likewise (scn_dense_terms_backward with dZ2 as aux),
+ *                     dW2[a][c] += relu(w1[a]) u_pos[c] + min(w1[a], 0) u_neg[c],
+ *                     dw1[a]    += [w1[a] > 0] (u_pos @ W2^T)[a] + [w1[a] < 0] (u_neg @ W2^T)[a]      (relu'(0) = 0, as everywhere). */
+int scn_split_sign(int64_t n, const float* g, float* g_pos, float* g_neg, void* stream);
+int scn_fold1_forward(const float* w1, const float* W2, int32_t c1, int32_t c2, float* a_pos, float* a_neg, void* stream);
+int scn_fold1_backward(const float* w1, const float* W2, const float* u_pos, const float* u_neg, int32_t c1, int32_t c2,
+                       float* dW2, float* dw1, void* stream);
 
 /* Scatter ragged edge flows into a zeroed slab tensor [n_slabs][n_edges][ns][1] (the flows_in input,
  * SDG:327-344): x[slab(n)][idx][n % ns] += val (repeated (trajectory, edge) entries accumulate, like the reference's

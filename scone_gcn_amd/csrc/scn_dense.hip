@@ -14,6 +14,7 @@ namespace scn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DN_MAX_TERMS = 3;
+constexpr int DN_MAX_TERMS1 = 6;      // the rank-one streaming kernels (every term ONE channel wide): three terms x (positive, negative part)
 constexpr int DN_THREADS = 256;
 
 struct DenseFwdArgs {
@@ -299,19 +300,26 @@ __global__ __launch_bounds__(256) void dense_fwd_out1_kernel(DenseFwdArgs a) {
 // thread = (point, 4 output channels), weights in registers, coalesced 16-byte stores -- a pure write stream.
 // (CG = c_out / 4 and the activation are template parameters: no run-time 64-bit division or activation switch per element,
 // -5 % on the composed Ebli first layer, -7 % on the Bunch one at |E| = 1M)
+struct DenseIn1Args {
+    int64_t n_points;
+    int32_t n_terms;
+    const float* G[DN_MAX_TERMS1];
+    const float* W[DN_MAX_TERMS1];
+    float* out;
+};
 template <int CG, int ACT>
-__global__ __launch_bounds__(256) void dense_fwd_in1_kernel(DenseFwdArgs a) {
+__global__ __launch_bounds__(256) void dense_fwd_in1_kernel(DenseIn1Args a) {
     static_assert(256 % CG == 0, "a thread keeps its channel group over the grid-stride loop");
     const int cq = threadIdx.x % CG;
-    f32x4 w[DN_MAX_TERMS];
+    f32x4 w[DN_MAX_TERMS1];
 #pragma unroll
-    for (int k = 0; k < DN_MAX_TERMS; ++k) w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < DN_MAX_TERMS1; ++k) w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t total = a.n_points * CG;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t pnt = i / CG;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < DN_MAX_TERMS; ++k)
+        for (int k = 0; k < DN_MAX_TERMS1; ++k)
             if (k < a.n_terms) v += a.G[k][pnt] * w[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply_fast(ACT, v[j]);
@@ -326,20 +334,20 @@ __global__ __launch_bounds__(256) void dense_fwd_in1_kernel(DenseFwdArgs a) {
 struct DenseBwdG1Args {
     int64_t n_points;
     int32_t n_terms, c_aux, act;
-    const float* G[DN_MAX_TERMS];
-    const float* W[DN_MAX_TERMS];
+    const float* G[DN_MAX_TERMS1];
+    const float* W[DN_MAX_TERMS1];
     const float* aux;
     float* dx;
     float* partial;
 };
 template <int CG, int ACT>                                        // CG = c_aux / 4 in {4, 8, 16}: 256 % CG == 0
 __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
-    __shared__ f32x4 red[DN_MAX_TERMS * 256];
+    __shared__ f32x4 red[DN_MAX_TERMS1 * 256];
     constexpr int cg = CG;
     const int cq = threadIdx.x % cg;
-    f32x4 w[DN_MAX_TERMS], acc[DN_MAX_TERMS];
+    f32x4 w[DN_MAX_TERMS1], acc[DN_MAX_TERMS1];
 #pragma unroll
-    for (int k = 0; k < DN_MAX_TERMS; ++k) {
+    for (int k = 0; k < DN_MAX_TERMS1; ++k) {
         w[k] = k < a.n_terms ? *(const f32x4*)(a.W[k] + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
         acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
         const f32x4 x = *(const f32x4*)(a.aux + i * 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < DN_MAX_TERMS; ++k)
+        for (int k = 0; k < DN_MAX_TERMS1; ++k)
             if (k < a.n_terms) {
                 const float g = a.G[k][pnt];
                 v += g * w[k];
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
         }
     }
 #pragma unroll
-    for (int k = 0; k < DN_MAX_TERMS; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    for (int k = 0; k < DN_MAX_TERMS1; ++k) red[k * 256 + threadIdx.x] = acc[k];
     __syncthreads();
     if ((int)threadIdx.x < a.n_terms * cg) {                        // threads with equal tid % cg hold the same channels
         const int k = threadIdx.x / cg, q = threadIdx.x - k * cg;
@@ -376,8 +384,8 @@ __global__ __launch_bounds__(256) void dense_bwd_g1_kernel(DenseBwdG1Args a) {
 struct DenseReduceArgs {
     const float* partial;
     int32_t n_partials, total, n_terms;
-    int32_t off[DN_MAX_TERMS + 1];
-    float* dW[DN_MAX_TERMS];
+    int32_t off[DN_MAX_TERMS1 + 1];
+    float* dW[DN_MAX_TERMS1];
 };
 __global__ void dense_dw_reduce(DenseReduceArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,6 +399,57 @@ __global__ void dense_dw_reduce(DenseReduceArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The first TWO Bunch layers without a 32-channel gather (scn_split_sign / scn_fold1_*; derivation in DESIGN.md):
+// bunch_func starts from [0, flow, 0] (TE:179), so the first layer's output of every level is relu of ONE rank-one term,
+//   H1_j[p][:] = relu(g_j[p] w_j) = max(g_j[p], 0) relu(w_j) + min(g_j[p], 0) min(w_j, 0),        g_j = S x  (one channel)
+// and the second layer's pre-activation is a sum of rank-one terms of SHIFTED SCALARS:
+//   (S_k H1_j) W_k = (S_k g_j^+)[p] (relu(w_j) W_k) + (S_k g_j^-)[p] (min(w_j, 0) W_k).
+// The shifts run on one-channel tensors, the expansion is dense_fwd_in1_kernel, and both layers' weight gradients follow from
+// u_k^(+/-) = sum_p (S_k g_j^(+/-))[p] dZ2[p][:] (dense_bwd_g1_kernel: one stream over dZ2) by the two folds below.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_sign_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ gp,
+                                                         float* __restrict__ gm) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        gp[i] = fmaxf(v, 0.f);
+        gm[i] = fminf(v, 0.f);
+    }
+}
+
+// Ap[c] = sum_a relu(w1[a]) W2[a][c],  Am[c] = sum_a min(w1[a], 0) W2[a][c]        (one workgroup, thread = output channel)
+__global__ void fold1_forward_kernel(const float* __restrict__ w1, const float* __restrict__ W2, int c1, int c2,
+                                     float* __restrict__ Ap, float* __restrict__ Am) {
+    const int c = threadIdx.x;
+    if (c >= c2) return;
+    float sp = 0.f, sm = 0.f;
+    for (int a = 0; a < c1; ++a) {
+        const float w = w1[a], v = W2[a * c2 + c];
+        sp = fmaf(fmaxf(w, 0.f), v, sp);
+        sm = fmaf(fminf(w, 0.f), v, sm);
+    }
+    Ap[c] = sp;
+    Am[c] = sm;
+}
+
+// dW2[a][c] += relu(w1[a]) up[c] + min(w1[a], 0) um[c]
+// dw1[a]    += [w1[a] > 0] sum_c up[c] W2[a][c] + [w1[a] < 0] sum_c um[c] W2[a][c]          (thread = row a of W2)
+__global__ void fold1_backward_kernel(const float* __restrict__ w1, const float* __restrict__ W2, const float* __restrict__ up,
+                                      const float* __restrict__ um, int c1, int c2, float* __restrict__ dW2,
+                                      float* __restrict__ dw1) {
+    const int a = threadIdx.x;
+    if (a >= c1) return;
+    const float w = w1[a], wp = fmaxf(w, 0.f), wm = fminf(w, 0.f);
+    float sp = 0.f, sm = 0.f;
+    for (int c = 0; c < c2; ++c) {
+        const float v = W2[a * c2 + c], p = up[c], m = um[c];
+        dW2[a * c2 + c] += wp * p + wm * m;
+        sp = fmaf(p, v, sp);
+        sm = fmaf(m, v, sm);
+    }
+    dw1[a] += (w > 0.f ? sp : 0.f) + (w < 0.f ? sm : 0.f);
+}
+
 static int dense_blocks(int64_t n_points) { return (int)std::min<int64_t>(2048, (n_points + DN_TILE - 1) / DN_TILE); }
 
 }  // namespace scn
@@ -402,7 +461,32 @@ extern "C" {
 int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* const* G, const int32_t* c_in,
                             const float* const* W, int32_t c_out, int32_t act, float* out, void* stream) {
     if (!G || !c_in || !W || !out) return SCN_ERR_BAD_ARG;
-    if (n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS || c_out <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS1 || c_out <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    {
+        bool in1 = c_out == 16 || c_out == 32 || c_out == 64;
+        for (int k = 0; k < n_terms; ++k) in1 = in1 && c_in[k] == 1;
+        if (in1) {                                                  // one-channel terms (up to DN_MAX_TERMS1 of them)
+            DenseIn1Args a1;
+            std::memset(&a1, 0, sizeof(a1));
+            a1.n_points = n_points; a1.n_terms = n_terms; a1.out = out;
+            for (int k = 0; k < n_terms; ++k) {
+                if (!G[k] || !W[k]) return SCN_ERR_BAD_ARG;
+                a1.G[k] = G[k]; a1.W[k] = W[k];
+            }
+            const int blocks = (int)std::min<int64_t>(8192, (n_points * (c_out / 4) + 255) / 256);
+#define SCN_LAUNCH_IN1(CG)                                                                                                   \
+    switch (act) {                                                                                                           \
+        case SCN_ACT_TANH: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_TANH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a1); break; \
+        case SCN_ACT_RELU: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_RELU>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a1); break; \
+        case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_LEAKY_RELU>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a1); break; \
+        default: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_NONE>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a1); break; \
+    }
+            if (c_out == 16) { SCN_LAUNCH_IN1(4) } else if (c_out == 32) { SCN_LAUNCH_IN1(8) } else { SCN_LAUNCH_IN1(16) }
+            SCN_LAUNCH_CHECK();
+            return SCN_OK;
+        }
+    }
+    if (n_terms > DN_MAX_TERMS) return SCN_ERR_BAD_SHAPE;
     DenseFwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_points = n_points; a.n_terms = n_terms; a.c_out = c_out; a.act = act; a.out = out;
@@ -426,21 +510,6 @@ int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* cons
         SCN_LAUNCH_CHECK();
         return SCN_OK;
     }
-    bool in1 = c_out == 16 || c_out == 32 || c_out == 64;
-    for (int k = 0; k < n_terms; ++k) in1 = in1 && c_in[k] == 1;
-    if (in1) {                                                      // one-channel terms
-        const int blocks = (int)std::min<int64_t>(8192, (n_points * (c_out / 4) + 255) / 256);
-#define SCN_LAUNCH_IN1(CG)                                                                                                   \
-    switch (act) {                                                                                                           \
-        case SCN_ACT_TANH: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_TANH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); break; \
-        case SCN_ACT_RELU: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_RELU>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); break; \
-        case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_LEAKY_RELU>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); break; \
-        default: hipLaunchKernelGGL((dense_fwd_in1_kernel<CG, SCN_ACT_NONE>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); break; \
-    }
-        if (c_out == 16) { SCN_LAUNCH_IN1(4) } else if (c_out == 32) { SCN_LAUNCH_IN1(8) } else { SCN_LAUNCH_IN1(16) }
-        SCN_LAUNCH_CHECK();
-        return SCN_OK;
-    }
     bool same = c_out == 1 && (c_in[0] == 16 || c_in[0] == 32);
     for (int k = 1; k < n_terms; ++k) same = same && c_in[k] == c_in[0];
     if (same) {                                                     // one output channel, equal term widths 16 / 32
@@ -460,7 +529,7 @@ int scn_dense_terms_forward(int64_t n_points, int32_t n_terms, const float* cons
 }
 
 size_t scn_dense_terms_backward_workspace(int64_t n_points, int32_t n_terms, const int32_t* c, int32_t c_aux) {
-    if (!c || n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS) return 0;
+    if (!c || n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS1) return 0;
     size_t tot = 0;
     for (int k = 0; k < n_terms; ++k) tot += (size_t)c_aux * c[k];
     return (size_t)std::max(dense_blocks(n_points), 1024) * tot * sizeof(float) + 256;   // (1024: the rank-one streaming kernel's grid)
@@ -470,8 +539,11 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
                              const float* const* W, const float* aux, int32_t c_aux, int32_t act, float* dx,
                              float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
     if (!G || !c || !W || !aux || !dW || !workspace) return SCN_ERR_BAD_ARG;
-    if (n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS || c_aux <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (n_points <= 0 || n_terms <= 0 || n_terms > DN_MAX_TERMS1 || c_aux <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     if (workspace_bytes < scn_dense_terms_backward_workspace(n_points, n_terms, c, c_aux)) return SCN_ERR_WORKSPACE;
+    bool all1 = c_aux == 16 || c_aux == 32 || c_aux == 64;
+    for (int k = 0; k < n_terms; ++k) all1 = all1 && c[k] == 1;
+    if (n_terms > DN_MAX_TERMS && !all1) return SCN_ERR_BAD_SHAPE;    // more than three terms: the rank-one stream only
     DenseBwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_points = n_points; a.n_terms = n_terms; a.c_aux = c_aux; a.act = act; a.aux = aux; a.dx = dx;
@@ -483,14 +555,12 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
     for (int k = 0; k < n_terms; ++k) {
         if (!G[k] || !W[k] || c[k] <= 0) return SCN_ERR_BAD_ARG;
         if (c_aux * c[k] > 4 * DN_THREADS) return SCN_ERR_UNSUPPORTED;
-        a.c[k] = c[k]; a.G[k] = G[k]; a.W[k] = W[k];
+        if (k < DN_MAX_TERMS) { a.c[k] = c[k]; a.G[k] = G[k]; a.W[k] = W[k]; }
         lds += (size_t)(c_aux * c[k] + DN_TILE * c[k]) * sizeof(float);
         r.off[k + 1] = r.off[k] + c_aux * c[k];
         r.dW[k] = dW[k];
     }
     hipStream_t st = (hipStream_t)stream;
-    bool all1 = c_aux == 16 || c_aux == 32 || c_aux == 64;
-    for (int k = 0; k < n_terms; ++k) all1 = all1 && c[k] == 1;
     if (all1) {                                                     // rank-one terms: the streaming kernel
         DenseBwdG1Args g;
         std::memset(&g, 0, sizeof(g));
@@ -529,6 +599,33 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
     SCN_LAUNCH_CHECK();
     r.partial = a.partial; r.n_partials = nb; r.total = r.off[n_terms]; r.n_terms = n_terms;
     hipLaunchKernelGGL(dense_dw_reduce, dim3((r.total + 255) / 256), dim3(256), 0, st, r);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_split_sign(int64_t n, const float* g, float* g_pos, float* g_neg, void* stream) {
+    if (!g || !g_pos || !g_neg) return SCN_ERR_BAD_ARG;
+    if (n <= 0) return SCN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(split_sign_kernel, dim3((int)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, g,
+                       g_pos, g_neg);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_fold1_forward(const float* w1, const float* W2, int32_t c1, int32_t c2, float* a_pos, float* a_neg, void* stream) {
+    if (!w1 || !W2 || !a_pos || !a_neg) return SCN_ERR_BAD_ARG;
+    if (c1 <= 0 || c2 <= 0 || c2 > 1024) return SCN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(fold1_forward_kernel, dim3(1), dim3((c2 + 63) / 64 * 64), 0, (hipStream_t)stream, w1, W2, c1, c2, a_pos, a_neg);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_fold1_backward(const float* w1, const float* W2, const float* u_pos, const float* u_neg, int32_t c1, int32_t c2,
+                       float* dW2, float* dw1, void* stream) {
+    if (!w1 || !W2 || !u_pos || !u_neg || !dW2 || !dw1) return SCN_ERR_BAD_ARG;
+    if (c1 <= 0 || c2 <= 0 || c1 > 1024) return SCN_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(fold1_backward_kernel, dim3(1), dim3((c1 + 63) / 64 * 64), 0, (hipStream_t)stream, w1, W2, u_pos, u_neg, c1, c2,
+                       dW2, dw1);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -76,6 +76,7 @@ def _nbytes(*tensors):
 # Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
 FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
 FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
+FOLD_BUNCH = True      # False: the first two Bunch layers as ordinary layers instead of the rank-one fold (BunchPlan._fold_forward)
 
 
 def _stream():
@@ -1067,7 +1068,12 @@ class BunchPlan:
                     need[i][BUNCH_SRC[k]] = True
         states, zeros = [cur], [zero]
         first_g = {}
-        for i in range(L):
+        self._fold = None
+        if self._fold_ok(x, weights, L, ns):
+            cur, zero = self._fold_forward(x, weights, need[2])
+            states += [[None] * 3, cur]                     # the first layer's output is never materialised
+            zeros += [[False] * 3, zero]
+        for i in range(2 if self._fold is not None else 0, L):
             nxt, nzero = [], []
             c_outs = {weights[7 * i + k].shape[1] for k in range(7)}
             c_ins = {cur[l].shape[3] for l in range(3) if not zero[l] and cur[l] is not None}
@@ -1123,6 +1129,72 @@ class BunchPlan:
         self._first_g = first_g
         return states
 
+    # -- the first TWO layers without a 32-channel gather --------------------------------------------------------------
+    # bunch_func starts from [0, flow, 0] (TE:179): after the first layer every level is relu of ONE rank-one term,
+    # H1_j = relu(g_j (x) w_j) with g_j = S_k1 x one channel wide (k1 = the slot that feeds level j from the edges), and
+    #     relu(g w) = max(g, 0) relu(w) + min(g, 0) min(w, 0)
+    # makes the second layer's pre-activation a sum of rank-one terms of SHIFTED SCALARS:
+    #     (S_k H1_j) W2_k = (S_k g_j^+) (x) (relu(w_j) W2_k)  +  (S_k g_j^-) (x) (min(w_j, 0) W2_k).
+    # So H1 is never formed: seven shifts of two one-channel tensors each (scn_spmm_dual), one rank-one expansion per level
+    # (scn_dense_terms_forward) -- and in the backward ONE stream over the second layer's pre-activation gradient per level
+    # (u_k^+- = sum_p (S_k g^+-)[p] dZ2[p][:], scn_dense_terms_backward) from which both layers' weight gradients follow by
+    # scn_fold1_backward.  Same sums as TE:183-195 in another association order; relu'(0) = 0 as everywhere here.
+    def _fold_ok(self, x, weights, L, ns):
+        if not (FOLD_BUNCH and FUSE_BUNCH and L >= 3 and x.shape[3] == 1 and self._blocked_ok(ns, 1)):
+            return False
+        c1 = {weights[k].shape[1] for k in range(7)}
+        c2 = {weights[7 + k].shape[1] for k in range(7)}
+        return len(c1) == 1 and len(c2) == 1 and next(iter(c2)) in (16, 32, 64) and all(weights[k].shape[0] == 1 for k in range(7))
+
+    def _fold_forward(self, x, weights, need2):
+        lib = _lib.load()
+        c1, c2 = weights[0].shape[1], weights[7].shape[1]
+        pm = {}                                            # level j -> (g^+, g^-, first-layer slot k1)
+        for k1 in range(7):
+            if BUNCH_SRC[k1] != 1:
+                continue                                   # the node and face levels start at zero: their slots contribute nothing
+            g = self._spmm(self.term_fwd[k1], x)
+            gp, gm = torch.empty_like(g), torch.empty_like(g)
+            check(lib.scn_split_sign(g.numel(), _dev(g), _dev(gp), _dev(gm), _stream()), "scn_split_sign")
+            pm[BUNCH_DST[k1]] = (gp, gm, k1)
+        terms, outs = {}, []
+        for lvl in range(3):
+            if not need2[lvl]:
+                outs.append(None)
+                continue
+            Gs, Ws = [], []
+            for k2 in self.fwd_slots[lvl]:
+                gp, gm, k1 = pm[BUNCH_SRC[k2]]
+                sp, sm = self._spmm(self.term_fwd[k2], gp), self._spmm(self.term_fwd[k2], gm)
+                ap = torch.empty((1, c2), device=x.device, dtype=torch.float32)
+                am = torch.empty_like(ap)
+                check(lib.scn_fold1_forward(_dev(weights[k1]), _dev(weights[7 + k2]), c1, c2, _dev(ap), _dev(am), _stream()),
+                      "scn_fold1_forward")
+                terms[k2] = (sp, sm, k1)
+                Gs += [sp, sm]
+                Ws += [ap, am]
+            outs.append(dense_terms_forward(Gs, Ws, c2, "relu"))
+        self._fold = terms
+        return outs, [o is None for o in outs]
+
+    def _fold_backward(self, fold, dz, dzero, weights, grads):
+        """Weight gradients of the first two layers from dz = the gradient of the second layer's pre-activation per level."""
+        lib = _lib.load()
+        c1, c2 = weights[0].shape[1], weights[7].shape[1]
+        for lvl in range(3):
+            if dzero[lvl] or dz[lvl] is None:
+                continue
+            ks = [k2 for k2 in self.fwd_slots[lvl] if k2 in fold]
+            Gs, us = [], []
+            for k2 in ks:
+                Gs += [fold[k2][0], fold[k2][1]]
+                us += [torch.zeros((c2, 1), device=dz[lvl].device, dtype=torch.float32) for _ in range(2)]
+            dense_terms_backward(Gs, us, dz[lvl], "none", False, us)       # us[q][c] = sum_p Gs[q][p] dz[p][c]  (W unused: no dx)
+            for q, k2 in enumerate(ks):
+                k1 = fold[k2][2]
+                check(lib.scn_fold1_backward(_dev(weights[k1]), _dev(weights[7 + k2]), _dev(us[2 * q]), _dev(us[2 * q + 1]), c1, c2,
+                                             _dev(grads[7 + k2]), _dev(grads[k1]), _stream()), "scn_fold1_backward")
+
     def promotion(self, weights):
         if len(weights) < 14 or len(weights) % 7:
             return None
@@ -1141,7 +1213,7 @@ class BunchPlan:
         check(lib.scn_node_readout_forward(S, ns, V, _dev(nodes_out), _dev(self.nbr, torch.int32), self.max_deg,
                                            _dev(last_dev, torch.int32), _dev(logits), _dev(logp), _stream()),
               "scn_node_readout_forward")
-        return logp, (states, self._zeros, self._first_g, wp)
+        return logp, (states, self._zeros, self._first_g, wp, self._fold)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         wp = saved[3]
@@ -1154,7 +1226,7 @@ class BunchPlan:
 
     def _backward(self, saved, logp, d_logp, last_dev, weights, grads):
         lib = _lib.load()
-        states, zeros, first_g, _ = saved
+        states, zeros, first_g, _, fold = saved
         nodes_out = states[-1][0]
         S, V, ns, _ = nodes_out.shape
         dz = [torch.empty_like(nodes_out), None, None]
@@ -1164,6 +1236,9 @@ class BunchPlan:
                                             ACT["relu"], _dev(dz[0]), _stream()), "scn_node_readout_backward")
         L = len(states) - 1
         for i in reversed(range(L)):
+            if i == 1 and fold is not None:             # the first two layers: no input gradients, one stream over dz per level
+                self._fold_backward(fold, dz, dzero, weights, grads)
+                break
             x, xzero = states[i], zeros[i]
             new_dz, new_zero = [None, None, None], [True, True, True]
             c_dz = {dz[l].shape[3] for l in range(3) if not dzero[l]}

@@ -48,6 +48,72 @@ def _n_samples(X):
     return len(X) if isinstance(X, SparseFlows) else X.shape[0]
 
 
+class _StaticStage:
+    """Device buffers with FIXED addresses for one host batch (what a captured graph replays on): the flow entries of up to
+    `cap_traj` trajectories as (trajectory, edge, value) triples, their last nodes and their targets -- filled through ONE pinned
+    host buffer and ONE host-to-device copy per step.  Unused entries carry value 0 (the scatter adds nothing), unused trajectories
+    have an all-zero flow and an all-zero target row (no loss, no gradient).  The targets are pre-scaled by 1 / (global batch
+    count), so the captured cross-entropy kernel's scale argument is the constant -1."""
+
+    def __init__(self, plan, X, D, cap_traj, device):
+        self.plan, self.X, self.D = plan, X, D
+        self.S = ops.pad_count(cap_traj) // ops.NS
+        self.n_cap = self.S * ops.NS
+        lens = np.sort(np.diff(X.ptr))[::-1]
+        self.e_cap = max(int(lens[:self.n_cap].sum()), 1)                    # entries of the longest n_cap trajectories
+        self.perm = plan.layout.perm[1].astype(np.int32)
+        E = plan.n_edges
+        n_words = 3 * self.e_cap + self.n_cap + self.n_cap * D
+        self.host = [torch.zeros(n_words, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.done = [None, None]
+        self.turn = 0
+        self.dev = torch.zeros(n_words, dtype=torch.int32, device=device)
+        e, n = self.e_cap, self.n_cap
+        self.sample_d, self.edge_d = self.dev[0:e], self.dev[e:2 * e]
+        self.val_d = self.dev[2 * e:3 * e].view(torch.float32)
+        self.last_d = self.dev[3 * e:3 * e + n]
+        self.y_d = self.dev[3 * e + n:].view(torch.float32).view(n, D)
+        self.x = torch.zeros((self.S, E, ops.NS, 1), device=device, dtype=torch.float32)
+        self.staged = (self.x, self.last_d, self.y_d, None)
+
+    def load(self, idx, last_nodes, y, total):
+        X, e, n = self.X, self.e_cap, self.n_cap
+        idx = np.asarray(idx)
+        m = len(idx)
+        starts = X.ptr[idx]
+        lens = X.ptr[idx + 1] - starts
+        k = int(lens.sum())
+        if m > n or k > e:
+            return False
+        t = self.turn
+        self.turn ^= 1
+        if self.done[t] is not None:
+            self.done[t].synchronize()                                   # the copy that last read this host buffer (two steps ago)
+        h = self.host[t].numpy()
+        h[:] = 0
+        if k:
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+            take = np.repeat(starts - off, lens) + np.arange(k)
+            h[0:k] = np.repeat(np.arange(m, dtype=np.int32), lens)
+            h[e:e + k] = self.perm[X.idx[take]]
+            h[2 * e:2 * e + k] = X.val[take].astype(np.float32).view(np.int32)
+        h[3 * e:3 * e + m] = np.asarray(last_nodes)[idx]
+        yv = (np.asarray(y)[idx].reshape(m, -1) / float(total)).astype(np.float32)
+        h[3 * e + n:3 * e + n + m * self.D] = yv.view(np.int32).ravel()
+        self.dev.copy_(self.host[t], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[t] = ev
+        return True
+
+    def scatter(self):
+        """x = the staged flows as slabs (captured into the graph: zero, then scatter-add of every entry)."""
+        self.x.zero_()
+        _lib.check(_lib.load().scn_scatter_flows(self.S, ops.NS, self.plan.n_edges, self.e_cap, ops._dev(self.sample_d, torch.int32),
+                                                 ops._dev(self.edge_d, torch.int32), ops._dev(self.val_d), ops._dev(self.x),
+                                                 ops._stream()), "scn_scatter_flows")
+
+
 class Scone_GCN():
     def __init__(self, epochs, step_size, batch_size, weight_decay, verbose=True, process_group=None, skip_mode="dense"):
         # skip_mode: "dense" (every block of every slab, the reference's formulation), "zeros" (skip work items whose
@@ -70,6 +136,11 @@ class Scone_GCN():
         self.model_type = 'scone'
         self._flat_w = self._flat_g = self._m = self._v = None
         self._step = 0
+        # launch-amortised step for small complexes (hipGraph replay, see _graph_accumulate): on by default, only ever used when
+        # the whole batch is one micro-batch of at most GRAPH_MAX_ELEMS activation elements
+        self.use_graph = True
+        self._graphs = {}
+        self._static = {}
 
     # ------------------------------------------------------------------ weights
     def generate_weights(self, in_channels, hidden_layers, out_channels):
@@ -103,6 +174,7 @@ class Scone_GCN():
         self._shapes = [tuple(w.shape) for w in host_weights]
         self.weights = self._views(self._flat_w)
         self._grads = self._views(self._flat_g)
+        self._graphs = {}                               # captured steps point at the previous buffers
 
     def _views(self, flat):
         return [flat[self._offsets[k]:self._offsets[k + 1]].view(self._shapes[k]) for k in range(len(self._shapes))]
@@ -246,16 +318,75 @@ class Scone_GCN():
     def _accumulate_grad(self, plan, inputs, y, idx, total):
         return self._accumulate_staged(plan, self.stage(inputs, y, idx), total)
 
+    # ------------------------------------------------------------------ launch-amortised step (hipGraph)
+    # On the reference's own problem sizes (TE:86-90: |E| = 1001, batch 100) one optimiser step is ~25 kernel launches of a few
+    # microseconds each: the step is bound by launch overhead, not by the kernels.  The device part of a step whose batch is a
+    # single micro-batch -- zero the gradient buffer, (scatter the input flows,) forward, readout, cross-entropy, backward -- is
+    # therefore captured ONCE into a HIP graph (torch.cuda.CUDAGraph: the C-ABI launches go to the capturing stream) and replayed;
+    # the gradient all-reduce and the fused ridge + Adam kernel (whose step index changes) stay ordinary launches behind it.
+    GRAPH_MAX_ELEMS = 1 << 22          # rows x trajectories x widest layer: beyond this the kernels dominate the step anyway
+    GRAPH_CACHE = 6
+
+    def _graph_ok(self, plan, n_traj):
+        if not self.use_graph or self.skip_mode != "dense" or ops.KernelTimer._stack:
+            return False
+        if type(plan) is not ops.SconePlan or plan._probed:
+            return False
+        widest = max(max(sh) for sh in self._shapes)
+        return plan.n_edges * ops.pad_count(n_traj) * (plan.promotion(self.weights) or widest) <= self.GRAPH_MAX_ELEMS
+
+    def _graph_accumulate(self, plan, staged, total, prologue=None, key_extra=()):
+        """flat_g = gradient of the staged micro-batch (as _accumulate_staged after zeroing flat_g), through a captured graph:
+        the first call with a given (plan, buffers, total, weight buffer) runs eagerly -- which also warms every kernel up --
+        and captures; later calls replay.  The buffers of `staged` must keep their addresses (they are kept alive here)."""
+        x, last_dev, yt, _ = staged[0]
+        key = (id(plan), x.data_ptr(), last_dev.data_ptr(), yt.data_ptr(), tuple(x.shape), float(total), self._flat_w.data_ptr(),
+               self._flat_g.data_ptr(), tuple(self._shapes)) + tuple(key_extra)
+        hit = self._graphs.get(key)
+        if hit is not None:
+            hit[0].replay()
+            return hit[1]
+
+        def body():
+            if prologue is not None:
+                prologue()
+            self._flat_g.zero_()
+            return self._accumulate_staged(plan, staged, total)
+        loss = body()                                    # eager: this call's result, and the warm-up of the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            part = body()
+        while len(self._graphs) >= self.GRAPH_CACHE:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = (g, part, staged, plan)
+        return loss
+
     def grad_step_staged(self, inputs, staged, total, apply=True):
         """grad_step on micro-batches already resident on the device (this rank's shard); `total` is the GLOBAL
         number of trajectories in the batch (all ranks)."""
         plan = self._plan(inputs)
-        self._flat_g.zero_()
-        loss = self._accumulate_staged(plan, staged, total)
+        if len(staged) == 1 and staged[0][3] is None and self._graph_ok(plan, staged[0][0].shape[0] * ops.NS):
+            loss = self._graph_accumulate(plan, staged, total)
+        else:
+            self._flat_g.zero_()
+            loss = self._accumulate_staged(plan, staged, total)
         dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
         if apply:
             self._adam()
         return loss
+
+    def _static_stage(self, plan, inputs, y):
+        """Fixed-address staging buffers for host batches of up to batch_size trajectories (the graph replays on them)."""
+        X = inputs[-1]
+        D = int(np.asarray(y).shape[1])
+        key = (id(plan), id(X), D, self.batch_size)
+        st = self._static.get(key)
+        if st is None:
+            if len(self._static) >= 4:
+                self._static.pop(next(iter(self._static)))
+            st = self._static[key] = _StaticStage(plan, X, D, self.batch_size, self._flat_w.device)
+        return st
 
     def grad_step(self, inputs, y, batch_mask, apply=True):
         """One optimiser step on the masked batch: gradient of self.loss (STM:307) + Adam update (STM:310, 326).
@@ -265,6 +396,16 @@ class Scone_GCN():
         plan = self._plan(inputs)
         if plan is None:
             return self._grad_step_autograd(inputs, y, idx, apply)
+        if isinstance(inputs[-1], SparseFlows) and len(idx) and self._graph_ok(plan, self.batch_size):
+            rank, ws = dp.world(self.process_group)
+            local = dp.shard_indices(idx, rank, ws)
+            st = self._static_stage(plan, inputs, y)
+            if st.load(local, inputs[1], y, len(idx)):        # False: more trajectories / flow entries than the buffers hold
+                loss = self._graph_accumulate(plan, [st.staged], 1.0, prologue=st.scatter, key_extra=("static",))
+                dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
+                if apply:
+                    self._adam()
+                return loss
         acc = {}
 
         def grad_fn(local, total):

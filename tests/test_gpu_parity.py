@@ -246,6 +246,42 @@ def test_bunch_fused_first_gradient_equals_the_separate_kernels(cfg1, sc1):
     assert max(np.abs(g).max() for g in grads[True][:7]) > 1e-4           # the first layer's gradients are not trivially zero
 
 
+@pytest.mark.parametrize("hidden", [32, 16])
+def test_bunch_rank_one_fold_equals_the_unfolded_layers(cfg1, sc1, hidden):
+    """BunchPlan._fold_forward / _fold_backward (the first two layers as shifts of one-channel tensors + rank-one expansions:
+    relu(g w) = g+ relu(w) + g- min(w, 0), the first layer's output never formed) against the same model with the two layers
+    run as ordinary layers: log-probabilities and all 28 weight gradients, and both against the oracle."""
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import trajectory_experiments as te
+    sel = np.arange(500, 523)
+    w = _rand_weights(so.weight_shapes(1, [(7, hidden)] * 3, 1, "bunch"), 0.4, 13)
+    X, y, last = cfg1["flows"][sel], cfg1["targets"][sel], cfg1["last_nodes"][sel]
+    shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
+    ref_loss, ref_g = so.bunch_loss_and_grad(w, [s_.csr for s_ in shifts], nbrhoods, last, X, y, np.ones(len(sel), int), 0.0)
+    yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
+    res = {}
+    keep = ops.FOLD_BUNCH
+    try:
+        for fold in (True, False):
+            ops.FOLD_BUNCH = fold
+            wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+            with ops.KernelTimer() as kt:
+                out = te.bunch_func(wt, *shifts, nbrhoods, last, X)
+                loss = -(out * yt).sum() / len(sel)
+                loss.backward()
+            assert any(k.startswith("dense_fwd x6") or k.startswith("dense_fwd x4") for k in kt.summary()) == fold
+            res[fold] = (out.detach().cpu().numpy(), float(loss.detach()), [t.grad.cpu().numpy().astype(np.float64) for t in wt])
+    finally:
+        ops.FOLD_BUNCH = keep
+    assert _maxdiff(res[True][0], res[False][0]) <= 2e-6
+    for k, (a, b) in enumerate(zip(res[True][2], res[False][2])):
+        assert _maxdiff(a, b) <= 2e-6 * max(1.0, np.abs(b).max()), "weight %d" % k
+    assert abs(res[True][1] - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(res[True][2][k], ref_g[k]) <= TOL, "weight %d" % k
+    assert max(np.abs(g_).max() for g_ in res[True][2][:14]) > 1e-4          # the two folded layers' gradients are not trivially zero
+
+
 def test_spmm_dual_matches_scipy(cfg1, sc1):
     from scone_gcn_amd import ops
     shifts = sc1.scone_shifts()
@@ -443,7 +479,8 @@ def test_spmm_blocks_without_sources():
 
 
 def test_bunch_on_a_complex_with_a_hub_node_falls_back_to_the_per_shift_path():
-    """A node of degree 110: its row of the concatenated Bunch operator has > 104 distinct sources, which the fused-layer plan
+    """A node of degree 60: its row of the concatenated Bunch operator has 121 > 104 distinct sources (itself, 60 neighbours, 60
+    incident edges; the readout kernels take neighbourhoods up to 64 wide, so 60 it is), which the fused-layer plan
     cannot hold (scn_terms_create -> SCN_ERR_UNSUPPORTED).  BunchPlan must then run every layer, forward AND backward, on the
     per-shift SpMM + dense-term path (it used to raise at hidden 32): loss and all 28 weight gradients against the oracle."""
     _need_gpu()
@@ -454,7 +491,7 @@ def test_bunch_on_a_complex_with_a_hub_node_falls_back_to_the_per_shift_path():
     from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
     base = g.random_SC_graph(700)
     hub = base.n_nodes
-    near = np.argsort(np.linalg.norm(base.coords - [0.5, 0.5], axis=1))[:110]
+    near = np.argsort(np.linalg.norm(base.coords - [0.5, 0.5], axis=1))[:60]
     inset = np.zeros(hub + 1, bool)
     inset[near] = True
     spokes = np.stack([near, np.full(len(near), hub)], axis=1)
@@ -464,7 +501,7 @@ def test_bunch_on_a_complex_with_a_hub_node_falls_back_to_the_per_shift_path():
                    faces=np.unique(np.concatenate([base.faces, cones]), axis=0),
                    coords=np.concatenate([base.coords, [[0.5, 0.5]]]))
     sc = SimplicialComplex(cx)
-    assert int(np.bincount(cx.edges.ravel()).max()) == 110
+    assert int(np.bincount(cx.edges.ravel()).max()) == 60
     paths = g.generate_random_walks(base, m=14, seed=5)                           # walks on the base complex (its edges all exist)
     flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=2)
     n = len(paths)
@@ -856,6 +893,48 @@ def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
     assert abs(loss - ref[2]) <= 1e-5 and acc == ref[3]
     t2 = net.two_target_accuracy(shifts, inputs, y, test_mask, n_nbrs)
     assert 0.0 <= t2 <= 1.0
+
+
+def test_graph_replayed_step_equals_the_eager_step(cfg1, sc1):
+    """The launch-amortised step of small complexes (Scone_GCN._graph_accumulate: the device part of an optimiser step captured
+    once into a HIP graph and replayed, host batches staged through fixed-address buffers) against the same steps launched
+    eagerly: the kernels, their order and their fixed-order reductions are the same, so losses, gradients and weights after
+    four Adam steps on four different batches must be IDENTICAL, for host batches (grad_step) and resident ones
+    (grad_step_staged)."""
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.synthetic_data_gen import SparseFlows
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    N = 1000
+    flows = SparseFlows(cfg1["flow_ptr"].astype(np.int64), cfg1["flow_idx"].astype(np.int64), cfg1["flow_val"].astype(np.float32), cfg1["E"])
+    inputs = [readout, cfg1["last_nodes"], flows]
+    y = cfg1["targets"]
+    res = {}
+    for graph in (False, True):
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-2, 100, 5e-5, verbose=False)
+        net.use_graph = graph
+        net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, cfg1["train_mask"], model_type="scone")
+        with torch.no_grad():
+            for w in net.weights:
+                w.mul_(20.0)
+        rs = np.random.RandomState(5)
+        out = []
+        for step in range(4):
+            m = np.zeros(N, int)
+            m[rs.choice(N, 100 - 7 * step, replace=False)] = 1            # batch sizes 100, 93, 86, 79: padding slabs too
+            net._step = step
+            loss = float(net.grad_step(inputs, y, m))
+            out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
+        staged = net.stage(inputs, y, np.arange(40, 104))
+        for step in range(3):                                              # resident micro-batch: first call eager + capture, then replays
+            loss = float(net.grad_step_staged(inputs, staged, 64))
+            out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
+        assert (len(net._graphs) > 0) == graph
+        res[graph] = out
+    for (la, ga, wa), (lb, gb, wb) in zip(res[False], res[True]):
+        assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
+    assert np.abs(res[True][0][1]).max() > 1e-5
 
 
 def test_train_loop_with_empty_batches(cfg1, sc1):
