@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=4096, help="trajectories per optimiser step over ALL ranks")
     ap.add_argument("--per-gpu-batch", type=int, default=0,
                     help="> 0: weak scaling instead -- this many trajectories per GPU (global batch = N x this)")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="trajectories in the sparse CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="trajectories in the sparse CPU-baseline sample (0 = skip)")
     ap.add_argument("--parity-sample", type=int, default=4, help="trajectories of the full-size oracle comparison (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0: headline only (no other configs, no SpMM, no skipping modes)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")
@@ -103,15 +103,19 @@ def cpu_baseline_sparse(cx, sc, flows, choice, last, hidden, n_sample):
     y = torch.tensor(so.onehot_targets(choice[sel], sc.max_degree), dtype=torch.float32)
     w = [torch.tensor(a, dtype=torch.float32) for a in so.generate_weights(1, [(3, hidden)] * 3, 1)]
     rows = ts.make_inc_rows(B1, sc.nbrhoods)
+    ts.loss_and_grad(w, Sl, Su, Sl, Su, rows, last[sel[:1]], X[:1], y[:1], 5e-5)      # warm-up: thread pool, sparse kernels, autograd
+    passes = 2
     t0 = time.perf_counter()
-    ts.loss_and_grad(w, Sl, Su, Sl, Su, rows, last[sel], X, y, 5e-5)
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    for _ in range(passes):
+        ts.loss_and_grad(w, Sl, Su, Sl, Su, rows, last[sel], X, y, 5e-5)
+    dt = (time.perf_counter() - t0) / passes
+    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(torch.get_num_threads()), "kind": "restatement",
             "dtype": "f32", "host_cpus": os.cpu_count(),
-            "sample": "%d trajectories of the same |E|=%d complex, hidden %d: reference formulation (TE:137-152, STM:42-56) "
+            "sample": "%d trajectories of the same |E|=%d complex, hidden %d: this repo's CPU restatement of the reference "
+                      "formulation (TE:137-152, STM:42-56; oracle/torch_sparse.py -- the reference's JAX code cannot run here) "
                       "in fp32 with torch.sparse_csr shifts (dense shifts do not exist at this size), forward + autograd "
-                      "backward, no optimiser, %d torch threads, %.1f s" % (n_sample, cx.n_edges, hidden,
-                                                                           torch.get_num_threads(), dt)}
+                      "backward, no optimiser, %d torch threads; one warm-up trajectory, then the mean of %d passes, %.1f s each"
+                      % (n_sample, cx.n_edges, hidden, torch.get_num_threads(), passes, dt)}
 
 
 def cpu_baseline_dense_cfg1(steps=2):
@@ -176,8 +180,10 @@ def oracle_parity(cx, sc, net, inputs, flows, choice, last, hidden, n_sample):
     got = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
     gmax = max(float(np.abs(r).max()) for r in ref_g)
     err = max(float(np.abs(a - b).max()) for a, b in zip(got, ref_g))
+    tol = 1e-5
     return {"n": n_sample, "max_err": max(err, abs(loss - ref_loss)), "loss_err": abs(loss - ref_loss), "grad_max_abs_err": err,
-            "grad_err_rel_to_max_grad": err / gmax, "max_abs_grad": gmax, "tol": 1e-5, "oracle_s": dt,
+            "grad_err_rel_to_max_grad": err / gmax, "max_abs_grad": gmax, "tol": tol, "oracle_s": dt,
+            "pass": bool(max(err, abs(loss - ref_loss)) <= tol),
             "oracle": "oracle/scone_oracle.py, fp64 NumPy + scipy CSR, same trajectories / weights, |E|=%d, hidden %d" % (cx.n_edges, hidden)}
 
 
@@ -220,19 +226,32 @@ def roofline_of(table, units_per_launch):
             "algorithmic_bytes_per_launch": r["alg_bytes"], "units_per_launch": units_per_launch}
 
 
+def measured_traffic(section, kernel_key):
+    """HBM bytes per launch of a timed kernel family from the committed rocprofv3 --pmc passes (profiles/r03_pmc_traffic.json:
+    2 * FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM; dense random tensors of the same launch shape)."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    sec = json.load(open(path)).get(section, {})
+    for name, row in sec.get("kernels", {}).items():
+        if kernel_key in row.get("timer_keys", []):
+            return row.get("hbm_bytes_per_launch"), "profiles/r03_pmc_traffic.json [%s] %s (%s)" % (section, name, sec.get("launch", ""))
+    return None, None
+
+
 def slim(table):
     return {k: {"launches": r["launches"], "avg_ms": round(r["avg_ms"], 4),
                 "GB/s": None if r["GB/s"] is None else round(r["GB/s"], 1)} for k, r in table.items()}
 
 
-def make_net(model, hidden, sc, flows, last, y, B, skip="dense"):
+def make_net(model, hidden, sc, flows, last, y, B, skip="dense", layers=None):
     from scone_gcn_amd import scone_trajectory_model as stm
     from scone_gcn_amd import trajectory_experiments as te
     shifts, readout, _ = te.setup_from_complex(sc, model)
     inputs = [readout, last, flows]
     stm.reseed(1030)
     net = stm.Scone_GCN(1, 1e-3, B, 5e-5, verbose=False, skip_mode=skip)
-    net.setup(te.MODEL_FUNCS[model], [(7 if model == "bunch" else 3, hidden)] * 3, shifts, inputs, y, None, np.ones(B, int),
+    net.setup(te.MODEL_FUNCS[model], layers or [(7 if model == "bunch" else 3, hidden)] * 3, shifts, inputs, y, None, np.ones(B, int),
               model_type=model)
     return net, inputs
 
@@ -246,12 +265,12 @@ def dataset(cx, sc, n, seed):
     return flows, choice, last, y
 
 
-def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data=None):
+def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data=None, layers=None, traffic_section=None):
     """One more BASELINE configuration on this GPU: step time, trajectories/s, its own dominant-kernel roofline."""
     import torch
     t0 = time.perf_counter()
     flows, choice, last, y = data if data is not None else dataset(cx, sc, batch, seed)
-    net, inputs = make_net(model, hidden, sc, flows, last, y, batch)
+    net, inputs = make_net(model, hidden, sc, flows, last, y, batch, layers=layers)
     staged = net.stage(inputs, y, np.arange(batch))
     mb = staged[0][0].shape[0] * 4
     torch.cuda.synchronize()
@@ -261,6 +280,13 @@ def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data
            "batch": batch, "micro_batch": mb, "steps": steps, "ms_per_step": dt / steps * 1e3,
            "value": batch * steps / dt, "unit": "trajectories/s", "plan": type(net._plan(inputs)).__name__,
            "roofline": roofline_of(table, mb), "kernels": slim(table), "setup_s": round(setup, 1)}
+    if layers:
+        out["hidden_layers"] = [list(l) for l in layers]
+    if out["roofline"] and traffic_section:
+        out["roofline"]["traffic"], src = measured_traffic(traffic_section, out["roofline"]["kernel"])
+        if src:
+            out["roofline"]["traffic_source"] = src
+    out["graph_replayed_step"] = bool(net._graphs)
     alg = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
     out["step_model"] = {"kernel_algorithmic_bytes_per_trajectory": alg / batch,
                          "frac_of_hbm_peak_whole_step": out["value"] * alg / batch / HBM_PEAK}
@@ -327,18 +353,11 @@ def main():
     dt, table = time_config(net, inputs, staged, total, args.steps, args.warmup, sync, all_max)
     value = total * args.steps / dt
     roofline = roofline_of(table, mb)
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/; same |E|, hidden and launch size only;
-    # measured on dense random tensors with tools/pmc_traffic.sh)
-    kmap = {"conv_bwd c32->32": "scn::bwd_c32_bf16_kernel", "conv_fwd c32->32": "scn::fwd_c32_w16_kernel",
-            "conv_fwd c1->32": "scn::fwd_c1_kernel"}
-    for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", tfile)
-        if roofline and os.path.exists(tpath) and roofline["kernel"] in kmap and E == 996634 and mb == 128:
-            t = json.load(open(tpath)).get(kmap[roofline["kernel"]], {}).get("hbm_bytes_per_launch")
-            if t:
-                roofline["traffic"] = t
-                roofline["traffic_source"] = "profiles/%s (2*FETCH_SIZE+WRITE_SIZE per launch, dense random tensors)" % tfile
-                break
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (same |E|, hidden and launch size only)
+    if roofline and E == 996634 and mb == 128 and C == 32:
+        t, src = measured_traffic("main", roofline["kernel"])
+        if t:
+            roofline["traffic"], roofline["traffic_source"] = t, src
     alg_step = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
     survey_bytes = 4.0 * E * (15 * C + 2)
     step_model = {"survey_model_bytes_per_trajectory": survey_bytes,
@@ -391,13 +410,13 @@ def main():
                               "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
                               "note": "same step, same results; work items whose values are exactly zero"
                                       + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
-            tf = os.path.join(ROOT, "profiles", "r01_skip_traffic.json")    # rocprofv3 --pmc passes of tools/pmc_skip.sh
+            tf = os.path.join(ROOT, "profiles", "r03_skip_traffic.json")    # rocprofv3 --pmc passes of tools/pmc_skip.sh (round-3 kernels)
             if os.path.exists(tf) and E == 996634 and C == 32:
                 meas = json.load(open(tf))
                 skipping[mode]["hbm_bytes_per_trajectory"] = {
                     "dense_model": survey_bytes, "measured_dense": meas["dense"]["hbm_bytes_per_trajectory"],
                     "measured_this_mode": meas[mode]["hbm_bytes_per_trajectory"],
-                    "source": "profiles/r01_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
+                    "source": "profiles/r03_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
             del st_m
         if skipping:
             line["zero_skipping"] = skipping
@@ -416,7 +435,9 @@ def main():
             dst.copy_(src)
         e1.record()
         torch.cuda.synchronize()
-        roofline["measured_copy_GBps"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        copy_gbps = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        if roofline:
+            roofline["measured_copy_GBps"] = copy_gbps
         del src, dst
         # the SpMM metric and the two fused C=32 kernels on DENSE RANDOM tensors (no zeros to favour clocks or caches)
         S = 32
@@ -438,9 +459,10 @@ def main():
                 for _ in range(3):
                     plan.conv.forward([xr], Wr, C, "tanh")
                     plan.conv.backward([xr], Wr, aux, "tanh", True, dWs)
-            line["roofline"]["dense_random"] = {
-                k: {"ms": r["avg_ms"], "GB/s": r["GB/s"], "frac": r["GB/s"] * 1e9 / HBM_PEAK}
-                for k, r in kt3.table().items()}
+            dense_random = {k: {"ms": r["avg_ms"], "GB/s": r["GB/s"], "frac": r["GB/s"] * 1e9 / HBM_PEAK}
+                            for k, r in kt3.table().items()}
+            if line["roofline"]:
+                line["roofline"]["dense_random"] = dense_random
             del Wr, aux, dWs
         del xr
         torch.cuda.empty_cache()
@@ -456,14 +478,20 @@ def main():
         configs = {}
         # configs[4]: Bunch (SCCONV), same complex, hidden 32, batch 1024; Ebli (SNN) beside it
         configs["configs[4] bunch"] = side_config("BASELINE configs[4]: -model bunch, |E|~1M, hidden 32, batch 1024", "bunch",
-                                                  cx, sc, 32, 1024, 2, sync)
-        configs["ebli"] = side_config("-model ebli (SNN), |E|~1M, hidden 32, batch 128", "ebli", cx, sc, 32, 128, 3, sync)
+                                                  cx, sc, 32, 1024, 2, sync, traffic_section="bunch")
+        configs["ebli"] = side_config("-model ebli (SNN), |E|~1M, hidden 32, batch 128", "ebli", cx, sc, 32, 128, 3, sync,
+                                      traffic_section="ebli")
+        # the reference's documented mixed-width stack (TE:51) on the same complex: runs on the hidden-32 kernels (promotion)
+        configs["mixed widths"] = side_config("-hidden_layers [(3,32),(3,16)] (TE:51), |E|~1M, batch 128", "scone", cx, sc, 32, 128, 3,
+                                              sync, layers=[(3, 32), (3, 16)])
+        configs["uniform 2x32"] = side_config("-hidden_layers [(3,32),(3,32)], |E|~1M, batch 128 (reference point for the mixed stack)",
+                                              "scone", cx, sc, 32, 128, 3, sync, layers=[(3, 32), (3, 32)])
         del plan, inputs
         # configs[1]: |E| ~ 50k, hidden 16, batch 1024
         cx2 = g.random_SC_graph(g.calibrate_n_points(50_000))
         sc2 = SimplicialComplex(cx2)
         configs["configs[1]"] = side_config("BASELINE configs[1]: synthetic |E|~50k, hidden 16, batch 1024", "scone", cx2, sc2,
-                                            16, 1024, 10, sync)
+                                            16, 1024, 10, sync, traffic_section="configs[1]")
         # configs[2]: ocean drifters, full training batch (the trajectories of tests/golden/buoy.npz)
         bpath = os.path.join(ROOT, "tests", "golden", "buoy.npz")
         if os.path.exists(bpath):

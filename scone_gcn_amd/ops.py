@@ -1154,9 +1154,10 @@ class BunchPlan:
             if BUNCH_SRC[k1] != 1:
                 continue                                   # the node and face levels start at zero: their slots contribute nothing
             g = self._spmm(self.term_fwd[k1], x)
-            gp, gm = torch.empty_like(g), torch.empty_like(g)
-            check(lib.scn_split_sign(g.numel(), _dev(g), _dev(gp), _dev(gm), _stream()), "scn_split_sign")
-            pm[BUNCH_DST[k1]] = (gp, gm, k1)
+            S = g.shape[0]
+            gpm = torch.empty((2 * S,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)   # [g^+ slabs | g^- slabs]
+            check(lib.scn_split_sign(g.numel(), _dev(g), _dev(gpm[:S]), _dev(gpm[S:]), _stream()), "scn_split_sign")
+            pm[BUNCH_DST[k1]] = (gpm, k1)
         terms, outs = {}, []
         for lvl in range(3):
             if not need2[lvl]:
@@ -1164,8 +1165,9 @@ class BunchPlan:
                 continue
             Gs, Ws = [], []
             for k2 in self.fwd_slots[lvl]:
-                gp, gm, k1 = pm[BUNCH_SRC[k2]]
-                sp, sm = self._spmm(self.term_fwd[k2], gp), self._spmm(self.term_fwd[k2], gm)
+                gpm, k1 = pm[BUNCH_SRC[k2]]
+                spm = self._spmm(self.term_fwd[k2], gpm)   # both parts in one launch: they are just more slabs of a one-channel tensor
+                sp, sm = spm[:spm.shape[0] // 2], spm[spm.shape[0] // 2:]
                 ap = torch.empty((1, c2), device=x.device, dtype=torch.float32)
                 am = torch.empty_like(ap)
                 check(lib.scn_fold1_forward(_dev(weights[k1]), _dev(weights[7 + k2]), c1, c2, _dev(ap), _dev(am), _stream()),

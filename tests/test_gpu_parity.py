@@ -210,9 +210,10 @@ def test_bunch_matches_oracle(cfg1, sc1, hidden):
     from scone_gcn_amd import ops
     with ops.KernelTimer() as kt:
         loss.backward()
-    if hidden == 32 and ops.FUSE_BUNCH and ops.FUSE_FIRST:
-        # the layer after the first one ran scn_terms_backward_fused_first (its input gradient is never written), the next one the plain fused backward
-        assert {"terms_bwd c32 + dW_first", "terms_bwd c32"} <= set(kt.summary())
+    if hidden == 32 and ops.FUSE_BUNCH and ops.FOLD_BUNCH:
+        # the third layer ran the fused three-level backward, the first two the rank-one fold (one stream over dZ2 per level)
+        assert {"terms_bwd c32", "dense_bwd x6", "dense_bwd x4"} <= set(kt.summary())
+        assert "terms_bwd c32 + dW_first" not in kt.summary()
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
@@ -229,8 +230,9 @@ def test_bunch_fused_first_gradient_equals_the_separate_kernels(cfg1, sc1):
     shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
     yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
     grads = {}
-    keep = ops.FUSE_FIRST
+    keep, keep_fold = ops.FUSE_FIRST, ops.FOLD_BUNCH
     try:
+        ops.FOLD_BUNCH = False                                  # (the default path folds the first two layers and needs neither)
         for fused in (True, False):
             ops.FUSE_FIRST = fused
             wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
@@ -240,7 +242,7 @@ def test_bunch_fused_first_gradient_equals_the_separate_kernels(cfg1, sc1):
             assert ("terms_bwd c32 + dW_first" in kt.summary()) == fused
             grads[fused] = [t.grad.cpu().numpy().astype(np.float64) for t in wt]
     finally:
-        ops.FUSE_FIRST = keep
+        ops.FUSE_FIRST, ops.FOLD_BUNCH = keep, keep_fold
     for k, (a, b) in enumerate(zip(grads[True], grads[False])):
         assert _maxdiff(a, b) <= 2e-6 * max(1.0, np.abs(b).max()), "weight %d" % k
     assert max(np.abs(g).max() for g in grads[True][:7]) > 1e-4           # the first layer's gradients are not trivially zero

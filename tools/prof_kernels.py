@@ -29,8 +29,9 @@ W = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
 W1 = [torch.randn(1, C, device=dev) * 0.1 for _ in range(3)]
 x = torch.randn(S, E, 4, C, device=dev)
 x1 = torch.randn(S, E, 4, 1, device=dev)
-aux = torch.tanh(torch.randn(S, E, 4, C, device=dev)) if "bwd" in a.which.split(",") else x   # a layer output, distinct from dz
+aux = torch.tanh(torch.randn(S, E, 4, C, device=dev)) if ("bwd" in a.which.split(",") or "bwdf" in a.which.split(",")) else x   # a layer output, distinct from dz
 which = a.which.split(",")
+yrec = torch.randn(S, E, 4, 4, device=dev) if "bwdf" in which else None
 def one_pass():
     if "spmm" in which:
         plan.conv.spmm_dual(x.view(S, E, 4 * C))
@@ -42,6 +43,8 @@ def one_pass():
         plan.conv.backward([x], W, aux, "tanh", True, [torch.zeros_like(w) for w in W])
     if "bwd1" in which:
         plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
+    if "bwdf" in which:             # the layer after the first one: fused with the first layer's weight gradient
+        assert plan.conv.backward_fused_first(x, W, aux, "tanh", yrec, [torch.zeros_like(w) for w in W], [torch.zeros_like(w) for w in W1])
     if "dwf" in which:
         assert plan.conv.dw_first(x1, None, x, [torch.zeros_like(w) for w in W1])
 

@@ -23,6 +23,12 @@ for s in "$@"; do
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
     pmc_c32)     step pmc_c32 400 bash tools/pmc_run.sh $OUT/pmc_c32 sq1,sq2,sq4 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
     pmc_c32_mem) step pmc_c32_mem 400 bash tools/pmc_run.sh $OUT/pmc_c32_mem fetch,write,tcc tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 2 ;;
+    pmc_main)    step pmc_main 400 bash tools/pmc_run.sh $OUT/pmc_main fetch,write,tcc tools/prof_kernels.py --which spmm,fwd,bwd,fwd1,bwdf --reps 2 ;;
+    pmc_cfg1)    step pmc_cfg1 300 bash tools/pmc_run.sh $OUT/pmc_cfg1 fetch,write,tcc tools/prof_kernels.py --edges 50000 --hidden 16 --slabs 256 --which fwd,bwd,fwd1,bwdf --reps 2 ;;
+    pmc_ebli)    step pmc_ebli 400 bash tools/pmc_run.sh $OUT/pmc_ebli fetch,write,tcc tools/prof_ebli.py --reps 2 ;;
+    pmc_bunch_mem) step pmc_bunch_mem 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc tools/prof_bunch.py --reps 2 ;;
+    pmc_skip)    step pmc_skip 900 bash tools/pmc_skip.sh $OUT/pmc_skip ;;
+    cfg0)        step cfg0 300 python3 tools/cfg1_step_time.py dense ;;
     spmm_ceiling) step spmm_ceiling 600 bash tools/spmm_ceiling.sh $OUT/spmm ;;
     bench)       step bench 900 python3 bench.py ;;
     bench_quick) step bench_quick 400 python3 bench.py --extras 0 --steps 5 --warmup 1 ;;
