@@ -287,7 +287,7 @@ int scn_terms_create(int32_t n_rows, const int32_t* rowptr, const int32_t* col, 
                      const int32_t* level_row0 /* [4] */,
                      const uint8_t* merged /* [n_rows]: level of the i-th simplex along ONE locality curve through all three
                                               levels (each level's rows in their own order): blocks are patches along it */,
-                     const int32_t* bins /* [3]: rows of each level a block may hold; multiples of rows_per_wave, sum <= 64 */,
+                     const int32_t* bins /* [3]: rows of each level a block may hold; multiples of rows_per_wave, sum <= 64; 0 = that level's rows belong to no block (its output is never asked for) */,
                      int32_t rows_per_wave /* 4: plan for scn_terms_forward, 8: for scn_terms_backward */, scn_conv_t* out);
 int scn_terms_forward(scn_conv_t op, int32_t n_slabs, int32_t ns, const float* const* x /* [3] */,
                       const float* const* W /* [9] = [class][term], each [32][32] */, int32_t channels, int32_t act,

@@ -997,6 +997,7 @@ class BunchPlan:
         self._dev_csr = dev
         self._generic = None
         self._terms = None                              # fused-layer operators (forward, transposed), built on first use
+        self._terms_nf = None                           # forward operator of a layer whose face output nothing reads
         nb = np.asarray(nbrhoods)
         pn = self.layout.perm[0]
         # padding index -1 wraps to the LAST node of the caller's numbering (TE:201); resolve it here, in device order
@@ -1033,6 +1034,24 @@ class BunchPlan:
                     raise
                 self._terms = False
         return self._terms or None
+
+    def _terms_fwd_for(self, want):
+        """Forward fused-layer operator for the wanted output levels: when the faces are not wanted (the layer before the last
+        one: TE:198-201 reads only the nodes of the last layer, which the faces do not feed) a plan whose blocks hold node and
+        edge rows only -- the face rows' share of every block goes to them (fewer blocks, fewer staged sources per output row)."""
+        fwd = self._terms_ops()[0]
+        if want[2] or not (want[0] and want[1]):
+            return fwd
+        if self._terms_nf is None:
+            dev = self._dev_csr
+            blocks = {(BUNCH_DST[k], BUNCH_SRC[k]): dev[k] for k in range(7) if BUNCH_DST[k] != 2}
+            try:
+                self._terms_nf = TermsOp(self.sizes, blocks, self.layout.merged, (16, 48, 0), 4)
+            except _lib.SconeHipError as e:
+                if e.status != _lib.SCN_ERR_UNSUPPORTED:
+                    raise
+                self._terms_nf = False
+        return self._terms_nf or fwd
 
     def _fused_ok(self, ns, widths_out, widths_in):
         return (FUSE_BUNCH and ns == NS and set(widths_out) == {32} and set(widths_in) == {32} and self._terms_ops() is not None)
@@ -1084,7 +1103,7 @@ class BunchPlan:
                 for k in range(7):
                     if xs[BUNCH_SRC[k]] is not None:
                         Ws[BUNCH_DST[k]][BUNCH_SRC[k]] = weights[7 * i + k]
-                outs = self._terms_ops()[0].forward(xs, Ws, "relu", need[i + 1])
+                outs = self._terms_fwd_for(need[i + 1]).forward(xs, Ws, "relu", need[i + 1])
                 cur, zero = outs, [o is None for o in outs]
                 states.append(cur)
                 zeros.append(zero)

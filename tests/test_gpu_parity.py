@@ -900,9 +900,10 @@ def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
 def test_graph_replayed_step_equals_the_eager_step(cfg1, sc1):
     """The launch-amortised step of small complexes (Scone_GCN._graph_accumulate: the device part of an optimiser step captured
     once into a HIP graph and replayed, host batches staged through fixed-address buffers) against the same steps launched
-    eagerly: the kernels, their order and their fixed-order reductions are the same, so losses, gradients and weights after
-    four Adam steps on four different batches must be IDENTICAL, for host batches (grad_step) and resident ones
-    (grad_step_staged)."""
+    eagerly.  Resident micro-batches (grad_step_staged) replay exactly the launches of the eager step: losses, gradients and
+    weights over three Adam steps must be IDENTICAL.  Host batches (grad_step) run on the staging buffers' fixed slab count
+    (unused trajectories: zero flow, zero target), so the weight-gradient partial sums are cut differently: equal to fp32
+    summation order (<= 2e-6 of the largest gradient entry) over four steps on four different batch sizes."""
     from scone_gcn_amd import scone_trajectory_model as stm
     from scone_gcn_amd import trajectory_experiments as te
     from scone_gcn_amd.synthetic_data_gen import SparseFlows
@@ -911,8 +912,8 @@ def test_graph_replayed_step_equals_the_eager_step(cfg1, sc1):
     flows = SparseFlows(cfg1["flow_ptr"].astype(np.int64), cfg1["flow_idx"].astype(np.int64), cfg1["flow_val"].astype(np.float32), cfg1["E"])
     inputs = [readout, cfg1["last_nodes"], flows]
     y = cfg1["targets"]
-    res = {}
-    for graph in (False, True):
+
+    def make(graph):
         stm.reseed(1030)
         net = stm.Scone_GCN(1, 1e-2, 100, 5e-5, verbose=False)
         net.use_graph = graph
@@ -920,23 +921,31 @@ def test_graph_replayed_step_equals_the_eager_step(cfg1, sc1):
         with torch.no_grad():
             for w in net.weights:
                 w.mul_(20.0)
+        return net
+    snap = lambda net, loss: (float(loss), net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy())
+    res = {}
+    for graph in (False, True):                                # resident micro-batch: first call eager + capture, then replays
+        net = make(graph)
+        staged = net.stage(inputs, y, np.arange(40, 104))
+        res[graph] = [snap(net, net.grad_step_staged(inputs, staged, 64)) for _ in range(3)]
+        assert (len(net._graphs) > 0) == graph
+    for (la, ga, wa), (lb, gb, wb) in zip(res[False], res[True]):
+        assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
+    assert np.abs(res[True][0][1]).max() > 1e-5
+    for graph in (False, True):                                # host batches of 100, 93, 86, 79 trajectories: padding slabs too
+        net = make(graph)
         rs = np.random.RandomState(5)
         out = []
         for step in range(4):
             m = np.zeros(N, int)
-            m[rs.choice(N, 100 - 7 * step, replace=False)] = 1            # batch sizes 100, 93, 86, 79: padding slabs too
+            m[rs.choice(N, 100 - 7 * step, replace=False)] = 1
             net._step = step
-            loss = float(net.grad_step(inputs, y, m))
-            out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
-        staged = net.stage(inputs, y, np.arange(40, 104))
-        for step in range(3):                                              # resident micro-batch: first call eager + capture, then replays
-            loss = float(net.grad_step_staged(inputs, staged, 64))
-            out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
+            out.append(snap(net, net.grad_step(inputs, y, m)))
         assert (len(net._graphs) > 0) == graph
         res[graph] = out
     for (la, ga, wa), (lb, gb, wb) in zip(res[False], res[True]):
-        assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
-    assert np.abs(res[True][0][1]).max() > 1e-5
+        gmax = np.abs(ga).max()
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la)) and np.abs(ga - gb).max() <= 2e-6 * gmax and np.abs(wa - wb).max() <= 2e-6
 
 
 def test_train_loop_with_empty_batches(cfg1, sc1):
@@ -1056,7 +1065,12 @@ def test_fused_bunch_layer_operator_matches_scipy(drop):
     for k in range(7):
         if live_in[SRC[k]]:
             Ws[DST[k]][SRC[k]] = t(Wk[k])
-    outs = fwd.forward(xt, Ws, "relu", want)
+    fop = plan._terms_fwd_for(want)
+    if drop == "no_faces_out":                       # its own plan: face rows belong to no block, node / edge rows fill them
+        assert fop is not fwd and fop.plan_info()[0] < fwd.plan_info()[0] and fop.bins == (16, 48, 0)
+    else:
+        assert fop is fwd
+    outs = fop.forward(xt, Ws, "relu", want)
     for l in range(3):
         if not want[l]:
             assert outs[l] is None
