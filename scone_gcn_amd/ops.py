@@ -1053,6 +1053,24 @@ class BunchPlan:
                 self._terms_nf = False
         return self._terms_nf or fwd
 
+    def _terms_bwd_for(self, dz_present):
+        """Transposed fused-layer operator for the levels whose gradient exists: when the faces carry none (the layer before the
+        last one: its face output was never computed) the two shifts INTO the faces are left out of the operator, so no block
+        spends staged sources on rows that are never staged."""
+        bwd = self._terms_ops()[1]
+        if dz_present[2] or not (dz_present[0] and dz_present[1]):
+            return bwd
+        if getattr(self, "_terms_bwd_nf", None) is None:
+            dev = self._dev_csr
+            blocks = {(BUNCH_SRC[k], BUNCH_DST[k]): dev[k].T.tocsr() for k in range(7) if BUNCH_DST[k] != 2}
+            try:
+                self._terms_bwd_nf = TermsOp(self.sizes, blocks, self.layout.merged, (16, 32, 16), 8)
+            except _lib.SconeHipError as e:
+                if e.status != _lib.SCN_ERR_UNSUPPORTED:
+                    raise
+                self._terms_bwd_nf = False
+        return self._terms_bwd_nf or bwd
+
     def _fused_ok(self, ns, widths_out, widths_in):
         return (FUSE_BUNCH and ns == NS and set(widths_out) == {32} and set(widths_in) == {32} and self._terms_ops() is not None)
 
@@ -1284,7 +1302,7 @@ class BunchPlan:
                     dWf = [grads[k_of[l]] if ys[l] is not None else None for l in range(3)]
                     _terms_backward_first(self._terms_ops()[1], dzs, Ws, auxs, "relu", ys, dWs, dWf)
                     break
-                dxs = _terms_backward(self._terms_ops()[1], dzs, Ws, auxs, "relu", want, dWs)
+                dxs = _terms_backward(self._terms_bwd_for([d is not None for d in dzs]), dzs, Ws, auxs, "relu", want, dWs)
                 dz, dzero = dxs, [d is None for d in dxs]
                 continue
             if i == 0 and FUSE_BUNCH and first_g and all(x[l] is None or x[l].shape[3] == 1 for l in range(3)):

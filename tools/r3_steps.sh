@@ -31,7 +31,12 @@ for s in "$@"; do
     pmc_ebli)    step pmc_ebli 400 bash tools/pmc_run.sh $OUT/pmc_ebli fetch,write,tcc tools/prof_ebli.py --reps 2 ;;
     pmc_bunch_mem) step pmc_bunch_mem 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc tools/prof_bunch.py --reps 2 ;;
     pmc_skip)    step pmc_skip 900 bash tools/pmc_skip.sh $OUT/pmc_skip ;;
-    cfg0)        step cfg0 300 python3 tools/cfg1_step_time.py dense ;;
+    cfg0)        step cfg0 300 python3 tools/cfg1_step_time.py dense breakdown ;;
+    small_step)  step small_graph 200 python3 tools/small_step.py
+                 step small_eager 200 python3 tools/small_step.py eager
+                 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+                 step small_graph_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_graph_prof -- python3 tools/small_step.py
+                 step small_eager_prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_eager_prof -- python3 tools/small_step.py eager ;;
     spmm_ceiling) step spmm_ceiling 600 bash tools/spmm_ceiling.sh $OUT/spmm ;;
     bench)       step bench 900 python3 bench.py ;;
     bench_quick) step bench_quick 400 python3 bench.py --extras 0 --steps 5 --warmup 1 ;;
