@@ -18,18 +18,33 @@ __device__ __forceinline__ float wave_max(float v) {
 
 constexpr int RO_MAXD = 64;   // max neighbourhood width handled by one wave (lane d)
 
-// one wave per trajectory
-__global__ __launch_bounds__(64) void readout_fwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
-                                                         const float* __restrict__ w, const int32_t* __restrict__ nbr,
-                                                         int max_deg, const int32_t* __restrict__ last_nodes,
-                                                         const int32_t* __restrict__ inc_ptr,
-                                                         const int32_t* __restrict__ inc_edge,
-                                                         const float* __restrict__ inc_sign,
-                                                         float* __restrict__ bh, float* __restrict__ logits,
-                                                         float* __restrict__ logp) {
-    const int n = blockIdx.x, lane = threadIdx.x;
+// ------------------------------------------------------------------------------------------------
+// Readout (TE:151-152 with Bconds_func TE:298-303) and its gradient, one wave per trajectory.
+// The work of a trajectory is a short ITEM list: (neighbour slot d, incident edge e of that neighbour, incidence sign).  It is
+// built first, with the lanes over slots / items (a chain of three dependent loads in all: nbr -> inc_ptr -> inc_edge), and
+// then consumed with the lanes over (item group, channel), every load independent of the others.  Walking slots and incident
+// edges serially with all lanes on one item -- the first form of these kernels, kept below for item lists that do not fit --
+// is a chain of ~4 dependent loads per item: 58 us per launch at |E| = 1001, which made the readout the dearest part of a
+// small-complex optimiser step.
+// ------------------------------------------------------------------------------------------------
+constexpr int RO_ITEMS = 512;   // items a trajectory's list can hold (max_deg x incident edges; 13 x ~7 on the reference's complexes)
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
+__device__ void readout_fwd_serial(int n, int lane, int ns, int n_edges, int c, const float* __restrict__ H,
+                                   const float* __restrict__ w, const int32_t* __restrict__ nbr, int max_deg, int vlast,
+                                   const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_edge,
+                                   const float* __restrict__ inc_sign, float* __restrict__ bh, float* __restrict__ logits,
+                                   float* __restrict__ logp) {
     const int s = n / ns, i = n - s * ns;
-    const int vlast = last_nodes[n];
     float my_logit = 0.f;   // lane d keeps logit d
     for (int d = 0; d < max_deg; ++d) {
         const int v = nbr[(size_t)vlast * max_deg + d];
@@ -61,33 +76,89 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(int ns, int n_edges, in
     }
 }
 
-__global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+__global__ __launch_bounds__(64) void readout_fwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
                                                          const float* __restrict__ w, const int32_t* __restrict__ nbr,
                                                          int max_deg, const int32_t* __restrict__ last_nodes,
                                                          const int32_t* __restrict__ inc_ptr,
                                                          const int32_t* __restrict__ inc_edge,
                                                          const float* __restrict__ inc_sign,
-                                                         const int32_t* __restrict__ edge_nodes,
-                                                         const float* __restrict__ d_logp,
-                                                         const float* __restrict__ logp, int act,
-                                                         float* __restrict__ dz, float* __restrict__ dl_out, int clear) {
-    // clear != 0: write zeros to exactly the dz entries the normal pass writes (scn_readout_clear_dz)
-    __shared__ float dl[RO_MAXD];
-    __shared__ int nb[RO_MAXD];
+                                                         float* __restrict__ bh, float* __restrict__ logits,
+                                                         float* __restrict__ logp) {
+    __shared__ int it_e[RO_ITEMS];
+    __shared__ float it_s[RO_ITEMS];
+    __shared__ int d_ptr[RO_MAXD + 1];
+    __shared__ float lgs[RO_MAXD];
     const int n = blockIdx.x, lane = threadIdx.x;
     const int s = n / ns, i = n - s * ns;
     const int vlast = last_nodes[n];
-    const float g = (!clear && lane < max_deg) ? d_logp[(size_t)n * max_deg + lane] : 0.f;
-    const float gs = wave_sum(g);
+    int start = 0, cnt = 0;
     if (lane < max_deg) {
-        if (!clear) {
-            const float v = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
-            dl[lane] = v;
-            dl_out[(size_t)n * max_deg + lane] = v;
+        const int v = nbr[(size_t)vlast * max_deg + lane];
+        if (v >= 0) {
+            start = inc_ptr[v];
+            cnt = inc_ptr[v + 1] - start;
         }
-        nb[lane] = nbr[(size_t)vlast * max_deg + lane];
+    }
+    const int off = wave_excl_scan(cnt, lane);
+    const int total = __shfl(off + cnt, 63, 64);
+    if (total > RO_ITEMS || c > 64) {                       // (wave-uniform)
+        readout_fwd_serial(n, lane, ns, n_edges, c, H, w, nbr, max_deg, vlast, inc_ptr, inc_edge, inc_sign, bh, logits, logp);
+        return;
+    }
+    if (lane < max_deg) d_ptr[lane] = off;
+    if (lane == 0) d_ptr[max_deg] = total;
+    for (int j = 0; j < cnt; ++j) {
+        it_e[off + j] = inc_edge[start + j];
+        it_s[off + j] = inc_sign[start + j];
     }
     __syncthreads();
+    const int cpad = c <= 16 ? 16 : (c <= 32 ? 32 : 64), G = 64 / cpad;
+    const int g = lane / cpad, cc = lane - g * cpad;
+    const float wc = cc < c ? w[cc] : 0.f;
+    const float* Hn = H + ((size_t)s * n_edges * ns + i) * c + cc;               // + e * ns * c
+    const size_t estride = (size_t)ns * c;
+    for (int d0 = 0; d0 < max_deg; d0 += G) {
+        const int d = d0 + g;
+        const bool live = d < max_deg && cc < c;
+        float acc = 0.f;
+        if (live) {
+            const int t0 = d_ptr[d], t1 = d_ptr[d + 1];
+            for (int t = t0; t < t1; t += 4) {             // four independent loads per trip, summed in list order
+                float h[4], sg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tu = t + u < t1 ? t + u : t;
+                    h[u] = Hn[(size_t)it_e[tu] * estride];
+                    sg[u] = t + u < t1 ? it_s[tu] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t + u < t1) acc = fmaf(sg[u], h[u], acc);
+            }
+            bh[((size_t)n * max_deg + d) * c + cc] = acc;
+        }
+        float lg = live ? acc * wc : 0.f;
+        for (int o = cpad >> 1; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);      // inside the aligned cpad-lane group
+        if (cc == 0 && d < max_deg) lgs[d] = lg;
+    }
+    __syncthreads();
+    const float my_logit = lane < max_deg ? lgs[lane] : 0.f;
+    const float x = lane < max_deg ? my_logit : -INFINITY;
+    const float m = wave_max(x);
+    const float se = wave_sum(lane < max_deg ? expf(x - m) : 0.f);
+    const float lse = m + logf(se);
+    if (lane < max_deg) {
+        logits[(size_t)n * max_deg + lane] = my_logit;
+        logp[(size_t)n * max_deg + lane] = my_logit - lse;
+    }
+}
+
+__device__ void readout_bwd_serial(int n, int lane, int ns, int n_edges, int c, const float* __restrict__ H,
+                                   const float* __restrict__ w, int max_deg, const int32_t* __restrict__ inc_ptr,
+                                   const int32_t* __restrict__ inc_edge, const float* __restrict__ inc_sign,
+                                   const int32_t* __restrict__ edge_nodes, int act, float* __restrict__ dz, int clear,
+                                   const float* dl, const int* nb) {
+    const int s = n / ns, i = n - s * ns;
     for (int d = 0; d < max_deg; ++d) {
         const int v = nb[d];
         if (v < 0) continue;
@@ -112,22 +183,108 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, in
     }
 }
 
-// d_w[c] += sum_{n,d} dl[n,d] * bh[n,d,c]: one block, 16 row-strided partial sums per channel combined in a fixed order
+__global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+                                                         const float* __restrict__ w, const int32_t* __restrict__ nbr,
+                                                         int max_deg, const int32_t* __restrict__ last_nodes,
+                                                         const int32_t* __restrict__ inc_ptr,
+                                                         const int32_t* __restrict__ inc_edge,
+                                                         const float* __restrict__ inc_sign,
+                                                         const int32_t* __restrict__ edge_nodes,
+                                                         const float* __restrict__ d_logp,
+                                                         const float* __restrict__ logp, int act,
+                                                         float* __restrict__ dz, float* __restrict__ dl_out, int clear) {
+    // clear != 0: write zeros to exactly the dz entries the normal pass writes (scn_readout_clear_dz)
+    __shared__ float dl[RO_MAXD];
+    __shared__ int nb[RO_MAXD];
+    __shared__ int d_ptr[RO_MAXD + 1], d_start[RO_MAXD];
+    __shared__ int it_e[RO_ITEMS];
+    __shared__ float it_coef[RO_ITEMS];
+    __shared__ unsigned char it_d[RO_ITEMS];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    const float g = (!clear && lane < max_deg) ? d_logp[(size_t)n * max_deg + lane] : 0.f;
+    const float gs = wave_sum(g);
+    int start = 0, cnt = 0;
+    if (lane < max_deg) {
+        if (!clear) {
+            const float v = g - expf(logp[(size_t)n * max_deg + lane]) * gs;
+            dl[lane] = v;
+            dl_out[(size_t)n * max_deg + lane] = v;
+        }
+        const int v = nbr[(size_t)vlast * max_deg + lane];
+        nb[lane] = v;
+        if (v >= 0) {
+            start = inc_ptr[v];
+            cnt = inc_ptr[v + 1] - start;
+        }
+    }
+    const int off = wave_excl_scan(cnt, lane);
+    const int total = __shfl(off + cnt, 63, 64);
+    __syncthreads();
+    if (total > RO_ITEMS || c > 64) {                       // (wave-uniform)
+        readout_bwd_serial(n, lane, ns, n_edges, c, H, w, max_deg, inc_ptr, inc_edge, inc_sign, edge_nodes, act, dz, clear, dl, nb);
+        return;
+    }
+    if (lane < max_deg) {
+        d_ptr[lane] = off;
+        d_start[lane] = start;
+    }
+    for (int j = 0; j < cnt; ++j) it_d[off + j] = (unsigned char)lane;
+    __syncthreads();
+    for (int t = lane; t < total; t += 64) {               // one item per lane: edge, skip rule, coefficient
+        const int d = it_d[t], v = nb[d];
+        const int j = d_start[d] + (t - d_ptr[d]);
+        const int e = inc_edge[j];
+        const int tl = edge_nodes[2 * e], hd = edge_nodes[2 * e + 1];
+        const int other = (tl == v) ? hd : tl;
+        int dk = -1;
+        for (int q = 0; q < max_deg; ++q)
+            if (nb[q] == other) dk = q;
+        const bool skip = dk >= 0 && other < v;            // handled from the other endpoint's side
+        it_e[t] = skip ? -1 : e;
+        // the two endpoints carry opposite incidence signs (B1[tail]=-1, B1[head]=+1; a flip scales both)
+        it_coef[t] = clear ? 0.f : inc_sign[j] * (dl[d] - (dk >= 0 ? dl[dk] : 0.f));
+    }
+    __syncthreads();
+    const int cpad = c <= 16 ? 16 : (c <= 32 ? 32 : 64), G = 64 / cpad;
+    const int gq = lane / cpad, cc = lane - gq * cpad;
+    const float wc = (!clear && cc < c) ? w[cc] : 0.f;
+    const size_t nbase = ((size_t)s * n_edges * ns + i) * c + cc, estride = (size_t)ns * c;
+    for (int t = gq; t < total; t += G) {
+        const int e = it_e[t];
+        if (e < 0 || cc >= c) continue;
+        const size_t o = nbase + (size_t)e * estride;
+        dz[o] = clear ? 0.f : it_coef[t] * wc * act_grad_from_output(act, H[o]);
+    }
+}
+
+// d_w[c] += sum_{n,d} dl[n,d] * bh[n,d,c]: one block; thread = (row group, channel) with 1024 / cpad row groups, each summing its
+// rows in order; the row groups are combined in a fixed order
 __global__ __launch_bounds__(1024) void readout_dw_kernel(int nd, int c, const float* __restrict__ dl,
                                                           const float* __restrict__ bh, float* __restrict__ d_w) {
-    __shared__ float part[16][64];
-    const int cc = threadIdx.x & 63, k = threadIdx.x >> 6;      // c <= 64 handled per launch chunk of 64 channels
+    __shared__ float part[1024];
     for (int c0 = 0; c0 < c; c0 += 64) {
+        const int cw = c - c0 < 64 ? c - c0 : 64;
+        const int cpad = cw <= 16 ? 16 : (cw <= 32 ? 32 : 64), K = 1024 / cpad;
+        const int k = threadIdx.x / cpad, cc = threadIdx.x - k * cpad;
         float acc = 0.f;
-        if (c0 + cc < c)
-            for (int q = k; q < nd; q += 16) acc = fmaf(dl[q], bh[(size_t)q * c + c0 + cc], acc);
-        part[k][cc] = acc;
+        if (cc < cw) {
+            int q = k;
+            for (; q + 3 * K < nd; q += 4 * K) {
+                const float a0 = dl[q], a1 = dl[q + K], a2 = dl[q + 2 * K], a3 = dl[q + 3 * K];
+                const float b0 = bh[(size_t)q * c + c0 + cc], b1 = bh[(size_t)(q + K) * c + c0 + cc],
+                            b2 = bh[(size_t)(q + 2 * K) * c + c0 + cc], b3 = bh[(size_t)(q + 3 * K) * c + c0 + cc];
+                acc = fmaf(a0, b0, acc); acc = fmaf(a1, b1, acc); acc = fmaf(a2, b2, acc); acc = fmaf(a3, b3, acc);
+            }
+            for (; q < nd; q += K) acc = fmaf(dl[q], bh[(size_t)q * c + c0 + cc], acc);
+        }
+        part[threadIdx.x] = acc;
         __syncthreads();
-        if (k == 0 && c0 + cc < c) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s += part[j][cc];
-            d_w[c0 + cc] += s;
+        if (k == 0 && cc < cw) {
+            float sum = 0.f;
+            for (int j = 0; j < K; ++j) sum += part[j * cpad + cc];
+            d_w[c0 + cc] += sum;
         }
         __syncthreads();
     }

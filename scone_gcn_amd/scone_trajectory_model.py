@@ -107,8 +107,7 @@ class _StaticStage:
         return True
 
     def scatter(self):
-        """x = the staged flows as slabs (captured into the graph: zero, then scatter-add of every entry)."""
-        self.x.zero_()
+        """x = the staged flows as slabs (captured into the graph: scn_scatter_flows zeroes x, then adds every entry)."""
         _lib.check(_lib.load().scn_scatter_flows(self.S, ops.NS, self.plan.n_edges, self.e_cap, ops._dev(self.sample_d, torch.int32),
                                                  ops._dev(self.edge_d, torch.int32), ops._dev(self.val_d), ops._dev(self.x),
                                                  ops._stream()), "scn_scatter_flows")
@@ -174,7 +173,14 @@ class Scone_GCN():
         self._shapes = [tuple(w.shape) for w in host_weights]
         self.weights = self._views(self._flat_w)
         self._grads = self._views(self._flat_g)
-        self._graphs = {}                               # captured steps point at the previous buffers
+        self._drop_graphs()                             # captured steps point at the previous buffers
+
+    def _drop_graphs(self, keep=0):
+        """Forget captured steps (oldest first) down to `keep`; a graph may still be replaying, so the device is drained first."""
+        if len(getattr(self, "_graphs", {})) > keep:
+            torch.cuda.synchronize()
+            while len(self._graphs) > keep:
+                self._graphs.pop(next(iter(self._graphs)))
 
     def _views(self, flat):
         return [flat[self._offsets[k]:self._offsets[k + 1]].view(self._shapes[k]) for k in range(len(self._shapes))]
@@ -357,8 +363,7 @@ class Scone_GCN():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             part = body()
-        while len(self._graphs) >= self.GRAPH_CACHE:
-            self._graphs.pop(next(iter(self._graphs)))
+        self._drop_graphs(self.GRAPH_CACHE - 1)
         self._graphs[key] = (g, part, staged, plan)
         return loss
 

@@ -16,7 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--edges", type=int, default=1_000_000)
 ap.add_argument("--slabs", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--which", default="fwd,bwd,bwdf")
+ap.add_argument("--which", default="fwd_nf,bwd_nf",
+                help="fwd / bwd / bwdf: all three levels in and out; fwd_nf / bwd_nf: the launches of the model's third layer (no face output, no face gradient)")
 a = ap.parse_args()
 cx = g.random_SC_graph(g.calibrate_n_points(a.edges))
 sc = SimplicialComplex(cx)
@@ -48,6 +49,15 @@ def one_pass():
         fwd.forward(xs, Wf, "relu", [True] * 3)
     if "bwd" in which:
         ops._terms_backward(bwd, xs, Wb, auxs, "relu", [True] * 3, dWb)
+    if "fwd_nf" in which:               # the layer before the last one: its face output is never asked for (own plan)
+        want = [True, True, False]
+        Wn = [[Wf[l][j] if l != 2 else None for j in range(3)] for l in range(3)]
+        plan._terms_fwd_for(want).forward(xs, Wn, "relu", want)
+    if "bwd_nf" in which:               # ... and the faces carry no gradient back into it
+        dzs = [xs[0], xs[1], None]
+        Wn = [[Wb[a][b] if b != 2 else None for b in range(3)] for a in range(3)]
+        dWn = [[dWb[a][b] if b != 2 else None for b in range(3)] for a in range(3)]
+        ops._terms_backward(plan._terms_bwd_for([True, True, False]), dzs, Wn, auxs, "relu", [True] * 3, dWn)
     if "bwdf" in which:
         ops._terms_backward_first(bwd, xs, Wb, auxs, "relu", ys, dWb, dWf)
 

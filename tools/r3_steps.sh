@@ -29,7 +29,7 @@ for s in "$@"; do
     pmc_main)    step pmc_main 400 bash tools/pmc_run.sh $OUT/pmc_main fetch,write,tcc tools/prof_kernels.py --which spmm,fwd,bwd,fwd1,bwdf --reps 2 ;;
     pmc_cfg1)    step pmc_cfg1 300 bash tools/pmc_run.sh $OUT/pmc_cfg1 fetch,write,tcc tools/prof_kernels.py --edges 50000 --hidden 16 --slabs 256 --which fwd,bwd,fwd1,bwdf --reps 2 ;;
     pmc_ebli)    step pmc_ebli 400 bash tools/pmc_run.sh $OUT/pmc_ebli fetch,write,tcc tools/prof_ebli.py --reps 2 ;;
-    pmc_bunch_mem) step pmc_bunch_mem 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc tools/prof_bunch.py --reps 2 ;;
+    pmc_bunch_mem) step pmc_bunch_mem 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2 tools/prof_bunch.py --reps 2 ;;
     pmc_skip)    step pmc_skip 900 bash tools/pmc_skip.sh $OUT/pmc_skip ;;
     cfg0)        step cfg0 300 python3 tools/cfg1_step_time.py dense breakdown ;;
     small_step)  step small_graph 200 python3 tools/small_step.py
