@@ -984,6 +984,7 @@ class BunchPlan:
         self.layout = shifts[0].layout
         self.device = device
         self.sizes = self.layout.sizes
+        self.n_edges = int(self.sizes[1])
         dev = [s.device_csr() for s in shifts]
         hints = self.layout.block_starts
         self.term_fwd = [ConvOp(self.sizes[BUNCH_DST[k]], [{"mats": [dev[k]], "identity": False,

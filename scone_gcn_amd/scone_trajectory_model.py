@@ -336,10 +336,11 @@ class Scone_GCN():
     def _graph_ok(self, plan, n_traj):
         if not self.use_graph or self.skip_mode != "dense" or ops.KernelTimer._stack:
             return False
-        if type(plan) is not ops.SconePlan or plan._probed:
+        if type(plan) not in (ops.SconePlan, ops.BunchPlan) or getattr(plan, "_probed", False):
             return False
         widest = max(max(sh) for sh in self._shapes)
-        return plan.n_edges * ops.pad_count(n_traj) * (plan.promotion(self.weights) or widest) <= self.GRAPH_MAX_ELEMS
+        rows = sum(plan.sizes) if type(plan) is ops.BunchPlan else plan.n_edges
+        return rows * ops.pad_count(n_traj) * (plan.promotion(self.weights) or widest) <= self.GRAPH_MAX_ELEMS
 
     def _graph_accumulate(self, plan, staged, total, prologue=None, key_extra=()):
         """flat_g = gradient of the staged micro-batch (as _accumulate_staged after zeroing flat_g), through a captured graph:

@@ -897,6 +897,49 @@ def test_train_loop_two_epochs_matches_oracle_trainer(cfg1, sc1):
     assert 0.0 <= t2 <= 1.0
 
 
+def test_graph_replayed_bunch_step_equals_the_eager_step(cfg1, sc1):
+    """The same for -model bunch (BunchPlan: fold, fused layers, node readout inside the captured graph): resident micro-batch
+    bitwise, host batches to summation order."""
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.synthetic_data_gen import SparseFlows
+    shifts, nbrhoods, _ = te.setup_from_complex(sc1, "bunch")
+    N = 1000
+    flows = SparseFlows(cfg1["flow_ptr"].astype(np.int64), cfg1["flow_idx"].astype(np.int64), cfg1["flow_val"].astype(np.float32), cfg1["E"])
+    inputs = [nbrhoods, cfg1["last_nodes"], flows]
+    y = cfg1["targets"]
+
+    def make(graph):
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-2, 60, 5e-5, verbose=False)
+        net.use_graph = graph
+        net.setup(te.bunch_func, [(7, 32)] * 3, shifts, inputs, y, None, cfg1["train_mask"], model_type="bunch")
+        with torch.no_grad():
+            for w in net.weights:
+                w.mul_(30.0)
+        return net
+    snap = lambda net, loss: (float(loss), net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy())
+    res = {}
+    for graph in (False, True):
+        net = make(graph)
+        staged = net.stage(inputs, y, np.arange(10, 58))
+        out = [snap(net, net.grad_step_staged(inputs, staged, 48)) for _ in range(3)]
+        rs = np.random.RandomState(3)
+        for step in range(3):
+            m = np.zeros(N, int)
+            m[rs.choice(N, 60 - 9 * step, replace=False)] = 1
+            net._step = 3 + step
+            out.append(snap(net, net.grad_step(inputs, y, m)))
+        assert (len(net._graphs) > 0) == graph
+        res[graph] = out
+    for k, ((la, ga, wa), (lb, gb, wb)) in enumerate(zip(res[False], res[True])):
+        if k < 3:
+            assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb), k
+        else:
+            assert abs(la - lb) <= 1e-6 * max(1.0, abs(la)) and np.abs(ga - gb).max() <= 2e-6 * np.abs(ga).max() and np.abs(wa - wb).max() <= 5e-6
+    assert np.abs(res[True][0][1]).max() > 1e-6
+
+
 def test_graph_replayed_step_equals_the_eager_step(cfg1, sc1):
     """The launch-amortised step of small complexes (Scone_GCN._graph_accumulate: the device part of an optimiser step captured
     once into a HIP graph and replayed, host batches staged through fixed-address buffers) against the same steps launched
