@@ -23,9 +23,6 @@ for s in "$@"; do
                  step ab_base 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_scalar.so step ab_scalar 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 3 ;;
     tests_spmm)  step tests_spmm 600 python3 -m pytest tests/test_gpu_fullsize_dense.py tests/test_gpu_parity.py -x -q -m gpu -k "spmm or rectangular or full_size_properties" ;;
-    ab_ring)     step ab_ring_build 300 bash tools/ab_build.sh ringdrain "-DSCN_AB_SPMM_RING_DRAINS"
-                 step ab_ring_new 200 python3 tools/prof_kernels.py --which spmm --reps 5
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ringdrain.so step ab_ring_old 200 python3 tools/prof_kernels.py --which spmm --reps 5 ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
     pmc_c32)     step pmc_c32 400 bash tools/pmc_run.sh $OUT/pmc_c32 sq1,sq2,sq4 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
