@@ -7,14 +7,18 @@
 //   LOCAL source slots (uint8) so the inner loop touches LDS only.  Rows are expected in a locality order
 //   (Hilbert order of the edge midpoints, scone_gcn_amd/complex.py) so a block's sources are ~2x its rows.
 //
-// Kernel structure: one 8-wave workgroup per CU, grid-strided over blocks with an XCD-contiguous mapping.
+// Kernel structure: one workgroup per CU (8 or 16 waves), grid-strided over blocks with an XCD-contiguous mapping.
 //   for block: ELL tile + source list -> LDS
 //     for slab: [s_waitcnt vmcnt(0); s_barrier]  -> slab s has landed in buffer s&1, everybody left buffer (s+1)&1
 //               issue LDS-DMA (global_load_lds, 16 B/lane, per-lane source = gather) of slab s+1 into the other buffer
-//               compute slab s: each wave gathers its 8 rows x 4 trajectories with lane = (point, channel slice)
-//               from the XOR-swizzled LDS image and feeds [self | lower | upper] straight into f32 MFMA against
-//               weights held in registers; the activation epilogue's stores are deferred by one slab so the next
-//               vmcnt(0) never waits on stores that were just issued.
+//               compute slab s: each wave gathers its rows x 4 trajectories with lane = (point, channel slice)
+//               from the XOR-swizzled LDS image and feeds [self | lower | upper] into bf16 MFMAs on an EXACT three-way
+//               split (hi + mid + lo = the fp32 value, six products, fp32 accumulation) against split weights in LDS;
+//               the activation epilogue's stores are deferred by one slab so the next vmcnt(0) never waits on stores
+//               that were just issued.
+// Parts (one translation unit): scn_blk_plan.inc (host: block plan), scn_blk_common.inc (LDS layout, gather, pipeline helpers),
+// scn_blk_spmm.inc (dual SpMM), scn_blk_fwd.inc / scn_blk_bwd.inc (fused layer kernels), scn_blk_first.inc (first-layer
+// gradient streams, reductions), scn_blk_dispatch.inc (host dispatch), scn_terms.inc (fused Bunch layer).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>

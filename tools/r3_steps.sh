@@ -31,6 +31,11 @@ for s in "$@"; do
     pmc_cfg1)    step pmc_cfg1 300 bash tools/pmc_run.sh $OUT/pmc_cfg1 fetch,write,tcc tools/prof_kernels.py --edges 50000 --hidden 16 --slabs 256 --which fwd,bwd,fwd1,bwdf --reps 2 ;;
     pmc_ebli)    step pmc_ebli 400 bash tools/pmc_run.sh $OUT/pmc_ebli fetch,write,tcc tools/prof_ebli.py --reps 2 ;;
     pmc_bunch_mem) step pmc_bunch_mem 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2 tools/prof_bunch.py --reps 2 ;;
+    pmc_main_bench) step pmc_main_bench 400 bash tools/pmc_run.sh $OUT/pmc_main_bench fetch,write,tcc tools/skip_step.py dense 2 512 ;;
+    bench_prof)  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+                 step bench_prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -- python3 bench.py --extras 0 ;;
+    gloo2)       step gloo2 600 python3 bench.py --gpus 2 --backend gloo --extras 0 --steps 2 --warmup 1 --global-batch 512 ;;
+    tests_durations) step tests_all 1150 python3 -m pytest tests -x -q -m gpu --durations=25 ;;
     pmc_skip)    step pmc_skip 900 bash tools/pmc_skip.sh $OUT/pmc_skip ;;
     cfg0)        step cfg0 300 python3 tools/cfg1_step_time.py dense breakdown ;;
     small_step)  step small_graph 200 python3 tools/small_step.py
