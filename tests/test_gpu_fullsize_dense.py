@@ -48,7 +48,7 @@ def scone_big(big_complex):
     return cx.n_edges, plan, lo, up
 
 
-@pytest.mark.parametrize("K,S", [(128, 3), (64, 3), (128, 17)])
+@pytest.mark.parametrize("K,S", [(128, 3), (64, 3), (64, 17)])
 def test_dual_spmm_every_row_against_scipy_at_one_million_edges(scone_big, K, S):
     """scn_spmm_dual (the four-stage ring kernel at K = 128 / 64; S = 3: the ring wraps inside one block visit, S = 17: a
     second visit of every block with a single slab) -- [L_low X, L_up X] (TE:146-147), all rows, all columns."""

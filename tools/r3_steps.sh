@@ -23,6 +23,16 @@ for s in "$@"; do
                  step ab_base 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_scalar.so step ab_scalar 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 3 ;;
     tests_spmm)  step tests_spmm 600 python3 -m pytest tests/test_gpu_fullsize_dense.py tests/test_gpu_parity.py -x -q -m gpu -k "spmm or rectangular or full_size_properties" ;;
+    terms_floor) step tf_build1 300 bash tools/ab_build.sh tfloor1 "-DSCN_TERMS_FLOOR=1"
+                 step tf_build2 300 bash tools/ab_build.sh tfloor2 "-DSCN_TERMS_FLOOR=2"
+                 step tf_base 300 python3 tools/prof_bunch.py --which fwd_nf --reps 3
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor1.so step tf_floor1 300 python3 tools/prof_bunch.py --which fwd_nf --reps 3
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor2.so step tf_floor2 300 python3 tools/prof_bunch.py --which fwd_nf --reps 3 ;;
+    fwd_floor)   step ff_build1 300 bash tools/ab_build.sh ffloor1 "-DSCN_FWD_FLOOR=1"
+                 step ff_build2 300 bash tools/ab_build.sh ffloor2 "-DSCN_FWD_FLOOR=2"
+                 step ff_base 300 python3 tools/prof_kernels.py --which fwd --reps 3
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor1.so step ff_floor1 300 python3 tools/prof_kernels.py --which fwd --reps 3
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor2.so step ff_floor2 300 python3 tools/prof_kernels.py --which fwd --reps 3 ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
     pmc_c32)     step pmc_c32 400 bash tools/pmc_run.sh $OUT/pmc_c32 sq1,sq2,sq4 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
