@@ -31,63 +31,13 @@ void set_hip_error(hipError_t e, const char* where);
     } while (0)
 
 // activation and its derivative expressed through the OUTPUT value y (what the backward has at hand)
-// tanh to ~2e-7 absolute: 1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32 for |x| >= 2^-9, the cubic x - x^3/3 below (relative
-// error < 1e-11 there), x itself for x == 0 (exact zeros stay exact zeros: the zero-propagation of this path relies on it).
-// Both paths sit behind WAVE-UNIFORM branches taken over all N values of a lane at once: a wave whose values are all exact
-// zeros (rows outside every trajectory's support: most of the benchmark's slabs) runs neither, a wave of dense data runs the
-// transcendental path only -- 4 VALU per value at 31 issue cycles, where the round-2 form (7th-order polynomial below 1/8,
-// select per value) ran both paths for nearly every wave: 12 VALU per value at 41 cycles, 6 on all-zero waves.
-template <int N>
-__device__ __forceinline__ void fast_tanh_n(float (&v)[N]) {
-#ifdef SCN_AB_TANH_V1                                              // diagnostic builds: the round-2 form
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float x = v[i], ax = fabsf(x), x2 = x * x;
-        const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
-        const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
-        const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
-        v[i] = ax < 0.125f ? poly : copysignf(r, x);
-    }
-#else
-    bool big[N];
-    unsigned long long any_big = 0, any_small = 0;                 // lane masks (SGPR pairs): two compares per value, the rest scalar
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        big[i] = fabsf(v[i]) >= 0x1p-9f;
-        const unsigned long long mb = __builtin_amdgcn_ballot_w64(big[i]);
-        any_big |= mb;
-        any_small |= ~mb & __builtin_amdgcn_fcmpf(v[i], 0.f, 14 /* une */);
-    }
-    if (any_big) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (big[i]) {
-                const float t = __builtin_amdgcn_exp2f(fabsf(v[i]) * 2.885390081777927f);
-                v[i] = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f), v[i]);
-            }
-    }
-    if (any_small) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (!big[i]) v[i] = fmaf(v[i] * v[i], v[i] * (-1.f / 3.f), v[i]);
-    }
-#endif
-}
+// tanh to ~3e-7 absolute: odd Taylor polynomial below 1/8, 1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32 above
 __device__ __forceinline__ float fast_tanh(float x) {
-    float v[1] = {x};
-    fast_tanh_n<1>(v);
-    return v[0];
-}
-// activation of N values of a lane at once (the tanh form shares its wave-uniform branches over them)
-template <int ACT, int N>
-__device__ __forceinline__ void act_apply_fast_n(float (&v)[N]) {
-    if (ACT == SCN_ACT_TANH) {
-        fast_tanh_n<N>(v);
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            v[i] = ACT == SCN_ACT_RELU ? fmaxf(v[i], 0.f) : (ACT == SCN_ACT_LEAKY_RELU ? (v[i] >= 0.f ? v[i] : 0.01f * v[i]) : v[i]);
-    }
+    const float ax = fabsf(x), x2 = x * x;
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
+    const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+    return ax < 0.125f ? poly : copysignf(r, x);
 }
 __device__ __forceinline__ float act_apply_fast(int act, float z) {
     switch (act) {
