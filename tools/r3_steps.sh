@@ -33,11 +33,6 @@ for s in "$@"; do
                  step ff_base 300 python3 tools/prof_kernels.py --which fwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor1.so step ff_floor1 300 python3 tools/prof_kernels.py --which fwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor2.so step ff_floor2 300 python3 tools/prof_kernels.py --which fwd --reps 3 ;;
-    ab_peel)     step ab_b1 300 bash tools/ab_build.sh nopeel "-DSCN_AB_GATHER_NO_PEEL"
-                 step ab_new 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_nopeel.so step ab_nopeel 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
-                 step bq_new 400 python3 bench.py --extras 0 --steps 5 --warmup 1
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_nopeel.so step bq_nopeel 400 python3 bench.py --extras 0 --steps 5 --warmup 1 ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
