@@ -324,6 +324,14 @@ int scn_terms_backward_fused_first(scn_conv_t op_t, int32_t n_slabs, int32_t ns,
 int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t identity, int32_t* order,
                           uint8_t* block_start);
 
+/* Host-only diagnostic (no device work, no reference counterpart): simulated LDS cost of one gather pass over the block plan
+ * of a SQUARE operator (pattern as for scn_plan_refine_order; val1, nnz floats or NULL, marks the second operator's entries;
+ * block_start as for scn_conv_create_blocked or NULL).  out4[0] = lane-group reads (one per quad of rows and entry position),
+ * out4[1] = their LDS cycles with the sources in row order and the entries in CSR order, out4[2] = with the plan's layout
+ * (slot colours + entry order, csrc/scn_blk_layout.inc; out4[2] == out4[0] means no bank conflict is left), out4[3] = blocks. */
+int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val1, int32_t identity,
+                          const uint8_t* block_start, int64_t* out4);
+
 /* Masked cross-entropy of one micro-batch (the data term of STM:54 and its gradient w.r.t. the log-probabilities):
  *   d_logp[i] = y[i] * scale   (scale = -1 / number of trajectories in the GLOBAL batch; padding rows have y = 0)
  *   loss[0]  += sum_i logp[i] * d_logp[i]    (fp64 accumulator on the device, fixed summation order)

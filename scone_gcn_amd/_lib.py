@@ -88,6 +88,7 @@ SIGNATURES = {
                                               ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_clear_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(WorkListDesc), c_void_p]),
     "scn_plan_refine_order": (ctypes.c_int, [c_i32, P_i32, P_i32, c_i32, P_i32, c_void_p]),
+    "scn_plan_gather_stats": (ctypes.c_int, [c_i32, P_i32, P_i32, c_void_p, c_i32, c_void_p, c_void_p]),
     "scn_conv_backward_fused_first_workspace": (c_size_t, [c_void_p, c_i32, c_i32, c_i32]),
     "scn_conv_backward_fused_first": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_i32,
                                                      c_i32, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p,

@@ -16,7 +16,7 @@
 //               split (hi + mid + lo = the fp32 value, six products, fp32 accumulation) against split weights in LDS;
 //               the activation epilogue's stores are deferred by one slab so the next vmcnt(0) never waits on stores
 //               that were just issued.
-// Parts (one translation unit): scn_blk_plan.inc (host: block plan), scn_blk_common.inc (LDS layout, gather, pipeline helpers),
+// Parts (one translation unit): scn_blk_layout.inc + scn_blk_plan.inc (host: block plan), scn_blk_common.inc (LDS layout, gather, pipeline helpers),
 // scn_blk_spmm.inc (dual SpMM), scn_blk_fwd.inc / scn_blk_bwd.inc (fused layer kernels), scn_blk_first.inc (first-layer
 // gradient streams, reductions), scn_blk_dispatch.inc (host dispatch), scn_terms.inc (fused Bunch layer).
 #include <algorithm>
@@ -48,6 +48,7 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP_FLUSH()
 #endif
 
+#include "scn_blk_layout.inc"
 #include "scn_blk_plan.inc"
 #include "scn_blk_common.inc"
 #include "scn_blk_spmm.inc"
@@ -62,7 +63,8 @@ __device__ unsigned long long g_stamps[8];
 
 // Host-only layout helper (no reference counterpart: the reference's dense operators have no storage order).
 // All lanes of a wave walk the ELL rows of their 8-row group to the group's widest row, so a block whose rows are sorted
-// by entry count wastes fewer gather iterations (1.25x -> 1.09x of nnz at |E| = 1M).  For a SQUARE pattern whose rows and
+// by entry count wastes fewer gather iterations (1.25x -> 1.09x of nnz at |E| = 1M); the sorted 8-row groups are then dealt to
+// the SIMDs evenly (see below).  For a SQUARE pattern whose rows and
 // columns share one index space: order[new] = old (rows only move inside the blocks the plan would cut) and
 // block_start[new] = 1 where those blocks begin -- pass it to scn_conv_create_blocked so the plan keeps exactly these cuts.
 extern "C" int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t identity, int32_t* order,
@@ -84,6 +86,46 @@ extern "C" int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int
         std::stable_sort(order + r0, order + r0 + rows, [&](int32_t a, int32_t b) {
             return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b];
         });
+        // the 8-row groups now come widest first, and wave i of a workgroup runs on SIMD i mod 4: the first four groups go in
+        // REVERSE (width ranks 3 2 1 0 4 5 6 7), so that the two groups a SIMD hosts in the 8-wave kernels -- and the four quads
+        // it hosts in the 16-wave kernels -- add up to about the same gather work (widest with narrowest, which may be cut short)
+        if (rows > 32) {
+            std::swap_ranges(order + r0, order + r0 + 8, order + r0 + 24);
+            std::swap_ranges(order + r0 + 8, order + r0 + 16, order + r0 + 16);
+        }
+        r0 += rows;
+    }
+    return SCN_OK;
+}
+
+// Host-only diagnostic (no GPU involved): the simulated LDS cost of one gather pass over a square operator's block plan --
+// lane-group reads (out[0]) and their LDS cycles with the sources in row order and the entries in CSR order (out[1]) and with
+// the plan's layout (out[2], scn_blk_layout.inc); out[3] = blocks.  val1 (nullable) marks the entries of the second operator.
+extern "C" int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val1, int32_t identity,
+                                     const uint8_t* block_start, int64_t* out4) {
+    if (n < 0 || !rowptr || !out4 || (n > 0 && !col && rowptr[n] > 0)) return SCN_ERR_BAD_ARG;
+    for (int64_t j = 0; j < rowptr[n]; ++j)
+        if (col[j] < 0 || col[j] >= n) return SCN_ERR_BAD_SHAPE;
+    std::vector<int32_t> mark(n, -1), local(n, 0), cur;
+    scn::BlockLayout L;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    int bid = 0;
+    for (int r0 = 0; r0 < n; ++bid) {
+        int rows = 0, w = 0, r_limit = n;
+        if (block_start)
+            for (int r = r0 + 1; r < std::min(n, r0 + scn::BK_R + 1); ++r)
+                if (block_start[r]) { r_limit = r; break; }
+        scn::grow_block(rowptr, col, r_limit, identity != 0, r0, bid, mark, cur, rows, w);
+        if (rows == 0) return SCN_ERR_UNSUPPORTED;
+        std::sort(cur.begin(), cur.end());
+        for (size_t i = 0; i < cur.size(); ++i) local[cur[i]] = (int32_t)i;
+        for (int mode = 0; mode < 2; ++mode) {
+            scn::layout_input(L, rowptr, col, val1, identity != 0, r0, rows, w, (int)cur.size(), local);
+            scn::layout_block(L, mode == 1);
+            out4[1 + mode] += L.cycles;
+        }
+        out4[0] += L.positions;
+        ++out4[3];
         r0 += rows;
     }
     return SCN_OK;

@@ -32,6 +32,24 @@ void set_hip_error(hipError_t e, const char* where);
 
 // activation and its derivative expressed through the OUTPUT value y (what the backward has at hand)
 // tanh to ~3e-7 absolute: odd Taylor polynomial below 1/8, 1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32 above
+#ifdef SCN_TANH_RATIONAL
+// branch-free: odd rational x P(x^2) / Q(x^2) on [-9, 9] (degrees 13 / 6, the float coefficients of the widely used minimax fit),
+// 13 plain VALU instructions + one v_rcp_f32 and no control flow, so the values of a tile interleave
+__device__ __forceinline__ float fast_tanh(float x) {
+    x = __builtin_amdgcn_fmed3f(x, -9.f, 9.f);
+    const float x2 = x * x;
+    float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+    p = fmaf(x2, p, -8.60467152213735e-11f);
+    p = fmaf(x2, p, 5.12229709037114e-08f);
+    p = fmaf(x2, p, 1.48572235717979e-05f);
+    p = fmaf(x2, p, 6.37261928875436e-04f);
+    p = fmaf(x2, p, 4.89352455891786e-03f);
+    float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+    q = fmaf(x2, q, 2.26843463243900e-03f);
+    q = fmaf(x2, q, 4.89352518554385e-03f);
+    return x * p * __builtin_amdgcn_rcpf(q);
+}
+#else
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x), x2 = x * x;
     const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
@@ -39,6 +57,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
     return ax < 0.125f ? poly : copysignf(r, x);
 }
+#endif
 __device__ __forceinline__ float act_apply_fast(int act, float z) {
     switch (act) {
         case SCN_ACT_TANH: return fast_tanh(z);
@@ -93,11 +112,11 @@ struct PlanDev {
     const int32_t* blk_row0;    // [n_blocks] first output row
     const uint8_t* blk_rows;    // [n_blocks] rows in block (<= BK_R)
     const int32_t* src_ptr;     // [n_blocks+1]
-    const int32_t* src_rows;    // staged source rows, ascending within a block
+    const int32_t* src_rows;    // staged source rows by slot (slot & 3 = the LDS bank class of the source: scn_blk_layout.inc)
     const int32_t* ell_ptr;     // [n_blocks] entry offset (entries are [t][BK_R])
     const uint8_t* width;       // [n_blocks] padded entries per row
     const uint8_t* tile_w;      // [n_blocks][BK_WAVES] entries needed by each wave's 8 rows
-    const uint8_t* tile_w4;     // [n_blocks][2*BK_WAVES] the same per 4 rows (16-wave kernels)
+    const uint8_t* tile_w4;     // [n_blocks][2*BK_WAVES] the same per QUAD: rows {0,3,5,6} / {1,2,4,7} of an 8-row group (16-wave kernels)
     const uint8_t* tile_wu;     // [n_blocks][BK_WAVES] leading entries that carry a non-zero val1 (rows are ordered that way)
     const int32_t* assign;      // optional [n_blocks]: visit position -> block (cost-balanced static assignment, per launch grid)
     const uint8_t* tile_wu4;    // [n_blocks][2*BK_WAVES]
@@ -131,6 +150,7 @@ struct BlockPlan {
     bool built = false;
     PlanDev dev{};
     double mean_src_per_row = 0.0;
+    int64_t gather_positions = 0, gather_cycles = 0;   // simulated lane-group reads of one gather pass and their LDS cycles (scn_blk_layout.inc)
     std::vector<int32_t> h_row0;   // first row of every block (+ n_rows): scn_conv_plan_blocks
     std::vector<float> h_cost;     // relative cost of one slab of every block (balanced_assignment)
     std::map<int, const int32_t*> assign_by_grid;   // grid.x -> device table, built with the plan

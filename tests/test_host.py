@@ -93,6 +93,33 @@ def test_layout_is_a_permutation_and_device_csr_is_conjugated(cx):
     assert np.array_equal(np.sort(sc2.layout.order[1]), np.arange(cx.n_edges))
 
 
+def test_block_layout_removes_most_lds_bank_conflicts_of_the_gather(cx):
+    """scn_plan_gather_stats (host-only): with the plan's slot colours and entry order a lane-group read of the gather costs
+    close to one LDS cycle; with slots in row order and entries in CSR order it costs close to two."""
+    import ctypes
+    from scone_gcn_amd import _lib
+    sc = SimplicialComplex(g.random_SC_graph(3000))
+    order, starts = sc.layout.order[1], sc.layout.block_starts[1]
+    lower, upper = abs(sc.B1.T @ sc.B1).tocsr(), abs(sc.B2 @ sc.B2.T).tocsr()
+    pat = (lower + upper).tocsr()[order][:, order].tocsr()
+    pat.sort_indices()
+    val1 = np.asarray(upper[order][:, order].tocsr()[pat.nonzero()]).ravel().astype(np.float32)
+    rowptr, col = np.ascontiguousarray(pat.indptr, np.int32), np.ascontiguousarray(pat.indices, np.int32)
+    as_p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    lib = _lib.load()
+    for v1, st in ((val1, starts), (None, None)):
+        out = np.zeros(4, np.int64)
+        _lib.check(lib.scn_plan_gather_stats(pat.shape[0], as_p(rowptr), as_p(col), None if v1 is None else v1.ctypes.data, 1,
+                                             None if st is None else st.ctypes.data, out.ctypes.data), "scn_plan_gather_stats")
+        reads, legacy, planned, blocks = (int(v) for v in out)
+        assert blocks >= pat.shape[0] // 64 and reads > 0
+        assert legacy > 1.5 * reads                       # the conflicts this layout is there to remove
+        assert reads <= planned < 1.2 * reads
+    bad = col.copy()
+    bad[0] = pat.shape[0]
+    assert lib.scn_plan_gather_stats(pat.shape[0], as_p(rowptr), as_p(bad), None, 1, None, out.ctypes.data) != 0
+
+
 def test_hilbert_index_is_a_bijection_on_a_grid():
     xs, ys = np.meshgrid(np.arange(16), np.arange(16))
     d = hilbert_index(xs.ravel(), ys.ravel(), order=4)

@@ -16,11 +16,12 @@ ap.add_argument("--hidden", type=int, default=32)
 ap.add_argument("--slabs", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--which", default="spmm,fwd,bwd,fwd1,bwd1")
+ap.add_argument("--act", default="tanh", help="activation of the timed layers (tanh | relu | leaky_relu | none)")
 a = ap.parse_args()
 cx = g.random_SC_graph(g.calibrate_n_points(a.edges))
 sc = SimplicialComplex(cx)
 shifts, readout, _ = te.setup_from_complex(sc, "scone")
-plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+plan = ops.get_scone_plan(shifts[0], shifts[1], readout, a.act, ops.default_device())
 print("plan blocks, sources/row:", plan.conv.plan_info(), flush=True)
 E, C, S = cx.n_edges, a.hidden, a.slabs
 torch.manual_seed(0)
@@ -36,24 +37,24 @@ def one_pass():
     if "spmm" in which:
         plan.conv.spmm_dual(x.view(S, E, 4 * C))
     if "fwd" in which:
-        plan.conv.forward([x], W, C, "tanh")
+        plan.conv.forward([x], W, C, a.act)
     if "fwd1" in which:
-        plan.conv.forward([x1], W1, C, "tanh")
+        plan.conv.forward([x1], W1, C, a.act)
     if "bwd" in which:
-        plan.conv.backward([x], W, aux, "tanh", True, [torch.zeros_like(w) for w in W])
+        plan.conv.backward([x], W, aux, a.act, True, [torch.zeros_like(w) for w in W])
     if "bwd1" in which:
-        plan.conv.backward([x], W1, x1, "tanh", False, [torch.zeros_like(w) for w in W1])
+        plan.conv.backward([x], W1, x1, a.act, False, [torch.zeros_like(w) for w in W1])
     if "bwdf" in which:             # the layer after the first one: fused with the first layer's weight gradient
-        assert plan.conv.backward_fused_first(x, W, aux, "tanh", yrec, [torch.zeros_like(w) for w in W], [torch.zeros_like(w) for w in W1])
+        assert plan.conv.backward_fused_first(x, W, aux, a.act, yrec, [torch.zeros_like(w) for w in W], [torch.zeros_like(w) for w in W1])
     if "dwf" in which:
         assert plan.conv.dw_first(x1, None, x, [torch.zeros_like(w) for w in W1])
 
 
 if "fwd" in which:              # checksums: A/B builds of a kernel must agree on these
-    print("checksum fwd %.9e" % float(plan.conv.forward([x], W, C, "tanh").double().abs().sum()), flush=True)
+    print("checksum fwd %.9e" % float(plan.conv.forward([x], W, C, a.act).double().abs().sum()), flush=True)
 if "bwd" in which:
     dWs = [torch.zeros_like(w) for w in W]
-    dxx = plan.conv.backward([x], W, aux, "tanh", True, dWs)
+    dxx = plan.conv.backward([x], W, aux, a.act, True, dWs)
     print("checksum bwd %.9e %.9e" % (float(dxx.double().abs().sum()), float(sum(d.double().abs().sum() for d in dWs))), flush=True)
 one_pass()                      # untimed warm-up (first launches set function attributes, fault in pages)
 torch.cuda.synchronize()
