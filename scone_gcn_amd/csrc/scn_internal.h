@@ -32,24 +32,6 @@ void set_hip_error(hipError_t e, const char* where);
 
 // activation and its derivative expressed through the OUTPUT value y (what the backward has at hand)
 // tanh to ~3e-7 absolute: odd Taylor polynomial below 1/8, 1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32 above
-#ifdef SCN_TANH_RATIONAL
-// branch-free: odd rational x P(x^2) / Q(x^2) on [-9, 9] (degrees 13 / 6, the float coefficients of the widely used minimax fit),
-// 13 plain VALU instructions + one v_rcp_f32 and no control flow, so the values of a tile interleave
-__device__ __forceinline__ float fast_tanh(float x) {
-    x = __builtin_amdgcn_fmed3f(x, -9.f, 9.f);
-    const float x2 = x * x;
-    float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
-    p = fmaf(x2, p, -8.60467152213735e-11f);
-    p = fmaf(x2, p, 5.12229709037114e-08f);
-    p = fmaf(x2, p, 1.48572235717979e-05f);
-    p = fmaf(x2, p, 6.37261928875436e-04f);
-    p = fmaf(x2, p, 4.89352455891786e-03f);
-    float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
-    q = fmaf(x2, q, 2.26843463243900e-03f);
-    q = fmaf(x2, q, 4.89352518554385e-03f);
-    return x * p * __builtin_amdgcn_rcpf(q);
-}
-#else
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x), x2 = x * x;
     const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
@@ -57,7 +39,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
     return ax < 0.125f ? poly : copysignf(r, x);
 }
-#endif
 __device__ __forceinline__ float act_apply_fast(int act, float z) {
     switch (act) {
         case SCN_ACT_TANH: return fast_tanh(z);

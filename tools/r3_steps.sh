@@ -40,11 +40,8 @@ for s in "$@"; do
                  step ab_new 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
                  step bq_new 400 python3 bench.py --extras 0 --steps 5 --warmup 1
                  step pmc_new 300 bash tools/pmc_run.sh $OUT/pmc_new sq2 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
-    ab_tanh)     step ab_tanh_base 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4
-                 step ab_tanh_relu 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4 --act relu
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tanhrat.so step ab_tanh_rat 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tanhrat.so step bq_tanh_rat 400 python3 bench.py --extras 0 --steps 5 --warmup 1
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tanhrat.so step tests_tanh_rat 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
+    ab_act)      step ab_act_tanh 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4
+                 step ab_act_relu 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4 --act relu ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
