@@ -20,6 +20,7 @@
 // scn_blk_spmm.inc (dual SpMM), scn_blk_fwd.inc / scn_blk_bwd.inc (fused layer kernels), scn_blk_first.inc (first-layer
 // gradient streams, reductions), scn_blk_dispatch.inc (host dispatch), scn_terms.inc (fused Bunch layer).
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>

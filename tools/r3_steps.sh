@@ -42,6 +42,21 @@ for s in "$@"; do
                  step pmc_new 300 bash tools/pmc_run.sh $OUT/pmc_new sq2 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
     ab_act)      step ab_act_tanh 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4
                  step ab_act_relu 200 python3 tools/prof_kernels.py --which fwd,fwd1 --reps 4 --act relu ;;
+    terms_check) step tests_bunch 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_dense.py -x -q -m gpu -k "bunch or Bunch or terms or poisoned"
+                 step prof_bunch 300 python3 tools/prof_bunch.py --reps 3
+                 step pmc_bunch_sq2 300 bash tools/pmc_run.sh $OUT/pmc_bunch_sq2 sq2 tools/prof_bunch.py --reps 2 ;;
+    ab_layout)   step abl_new_bunch 300 python3 tools/prof_bunch.py --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl_old_bunch 300 python3 tools/prof_bunch.py --reps 4
+                 step abl_new_bunch2 300 python3 tools/prof_bunch.py --reps 4
+                 step abl_new_c32 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl_old_c32 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
+                 step abl_new_bq 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl_old_bq 400 python3 bench.py --extras 0 --steps 5 --warmup 1 ;;
+    ab_layout2)  step abl2_new_bunch 300 python3 tools/prof_bunch.py --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl2_old_bunch 300 python3 tools/prof_bunch.py --reps 4
+                 step abl2_new_bunch2 300 python3 tools/prof_bunch.py --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl2_old_bunch2 300 python3 tools/prof_bunch.py --reps 4
+                 step tests_bunch 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_dense.py -x -q -m gpu -k "bunch or Bunch or terms or poisoned" ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
