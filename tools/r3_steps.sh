@@ -57,6 +57,12 @@ for s in "$@"; do
                  step abl2_new_bunch2 300 python3 tools/prof_bunch.py --reps 4
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_legacy.so step abl2_old_bunch2 300 python3 tools/prof_bunch.py --reps 4
                  step tests_bunch 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_dense.py -x -q -m gpu -k "bunch or Bunch or terms or poisoned" ;;
+    ab_base)     for r in 1 2; do
+                   step abb_new_c32_$r 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step abb_old_c32_$r 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
+                   step abb_new_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step abb_old_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                 done ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
