@@ -81,3 +81,32 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "scone_hip.h"\nint main(void) { scn_work_list w = {0, 0, 0, 0}; (void)w; return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
+def test_compiler_never_touches_m0_in_kernels_with_inline_assembly_lds_dma(tmp_path):
+    """The fused kernels issue their LDS-DMA as inline assembly that writes M0 (csrc/scn_blk_common.inc, lds_dma16) without
+    telling the compiler (M0 is a reserved register: it cannot be listed as clobbered).  That is only sound while the compiler
+    itself has no use for M0 in those kernels: compile the translation unit to device assembly and check every kernel that
+    contains such a block for M0 outside of the blocks (kernels on the builtin LDS-DMA use M0 themselves and must have none)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "scn_blocked.s"
+    csrc = os.path.join(ROOT, "scone_gcn_amd", "csrc")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                           "-S", "--cuda-device-only", "-o", str(out), os.path.join(csrc, "scn_blocked.hip")],
+                          stderr=subprocess.DEVNULL)
+    asm = out.read_text()
+    kernels = re.split(r"\n(?=_ZN3scn[^\n]*:\s*; @)", asm)
+    with_blocks = 0
+    for k in kernels:
+        m = re.match(r"(_ZN3scn\S+):", k)
+        if not m:
+            continue
+        body = k.split("s_endpgm")[0]
+        outside = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", body, flags=re.S)
+        inside = len(re.findall(r"\bm0\b", body)) - len(re.findall(r"\bm0\b", outside))
+        if inside:
+            with_blocks += 1
+            assert not re.search(r"\bm0\b", outside), m.group(1) + ": the compiler uses M0 next to an inline-assembly LDS-DMA"
+    assert with_blocks >= 20          # forward, backward, fused Bunch and ring SpMM instantiations

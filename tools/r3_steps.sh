@@ -63,6 +63,26 @@ for s in "$@"; do
                    step abb_new_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
                    SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step abb_old_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
                  done ;;
+    ab_base_bunch) for r in 1 2; do
+                   step abbb_new_$r 300 python3 tools/prof_bunch.py --reps 4
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step abbb_old_$r 300 python3 tools/prof_bunch.py --reps 4
+                 done ;;
+    ab_three)    for r in 1 2; do
+                   step ab3_new_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab3_old_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_peel.so step ab3_peel_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                 done
+                 step ab3_new_c32 200 python3 tools/prof_kernels.py --which fwd,bwd,fwd1 --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab3_old_c32 200 python3 tools/prof_kernels.py --which fwd,bwd,fwd1 --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_peel.so step ab3_peel_c32 200 python3 tools/prof_kernels.py --which fwd,bwd,fwd1 --reps 4 ;;
+    ab_four)     for r in 1 2; do
+                   step ab4_new_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_bq_$r 400 python3 bench.py --extras 0 --steps 5 --warmup 1
+                 done
+                 step ab4_new_c32 200 python3 tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_c32 200 python3 tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 4
+                 step ab4_new_bunch 300 python3 tools/prof_bunch.py --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_bunch 300 python3 tools/prof_bunch.py --reps 4 ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
