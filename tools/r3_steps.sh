@@ -83,6 +83,7 @@ for s in "$@"; do
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_c32 200 python3 tools/prof_kernels.py --which spmm,fwd,bwd,fwd1 --reps 4
                  step ab4_new_bunch 300 python3 tools/prof_bunch.py --reps 4
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_bunch 300 python3 tools/prof_bunch.py --reps 4 ;;
+    tests_bunch) step tests_bunch 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_dense.py -x -q -m gpu -k "bunch or Bunch or terms or poisoned" ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
