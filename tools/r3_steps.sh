@@ -84,6 +84,13 @@ for s in "$@"; do
                  step ab4_new_bunch 300 python3 tools/prof_bunch.py --reps 4
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_base.so step ab4_old_bunch 300 python3 tools/prof_bunch.py --reps 4 ;;
     tests_bunch) step tests_bunch 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_dense.py -x -q -m gpu -k "bunch or Bunch or terms or poisoned" ;;
+    floors_prebuilt) SCN_CEILING_PREBUILT=1 step spmm_ceiling 500 bash tools/spmm_ceiling.sh $OUT/spmm
+                 step ff_base 200 python3 tools/prof_kernels.py --which fwd --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor1.so step ff_floor1 200 python3 tools/prof_kernels.py --which fwd --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor2.so step ff_floor2 200 python3 tools/prof_kernels.py --which fwd --reps 4
+                 step tf_base 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor1.so step tf_floor1 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
+                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor2.so step tf_floor2 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4 ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;

@@ -8,8 +8,10 @@ set -e
 OUT=$1
 cd $GRAFT_REPO_ROOT
 mkdir -p $OUT
-bash tools/ab_build.sh floor1 "-DSCN_SPMM_FLOOR=1" > $OUT/build1.log 2>&1
-bash tools/ab_build.sh floor2 "-DSCN_SPMM_FLOOR=2" > $OUT/build2.log 2>&1
+if [ -z "$SCN_CEILING_PREBUILT" ]; then     # (set it when tools/ab/lib_floor{1,2}.so were cross-compiled from this tree before the snapshot)
+  bash tools/ab_build.sh floor1 "-DSCN_SPMM_FLOOR=1" > $OUT/build1.log 2>&1
+  bash tools/ab_build.sh floor2 "-DSCN_SPMM_FLOOR=2" > $OUT/build2.log 2>&1
+fi
 python3 tools/prof_kernels.py --which spmm --reps 5 > $OUT/time_product.log 2>&1
 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_floor1.so python3 tools/prof_kernels.py --which spmm --reps 5 > $OUT/time_floor1.log 2>&1
 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_floor2.so python3 tools/prof_kernels.py --which spmm --reps 5 > $OUT/time_floor2.log 2>&1
