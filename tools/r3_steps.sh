@@ -92,6 +92,11 @@ for s in "$@"; do
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor1.so step tf_floor1 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_tfloor2.so step tf_floor2 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4 ;;
     smoke)       step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ;;
+    ab_pf)       for r in 1 2; do
+                   step abpf_new_$r 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_pf2.so step abpf_pf2_$r 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
+                   SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_pfoff.so step abpf_off_$r 300 python3 tools/prof_bunch.py --which fwd_nf --reps 4
+                 done ;;
     tests_quick) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu ;;
     tests_all)   step tests_all 1100 python3 -m pytest tests -x -q -m gpu ;;
     pmc_bunch)   step pmc_bunch 500 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc,sq1,sq2,sq4 tools/prof_bunch.py --reps 2 ;;
