@@ -36,6 +36,7 @@ extern "C" {
 #define SCN_ERR_UNSUPPORTED -4
 #define SCN_ERR_NOMEM       -5
 #define SCN_ERR_WORKSPACE   -6
+#define SCN_ERR_INTERNAL    -7   /* a self-check of the library failed (scn_plan_gather_stats: the block layout lost or moved an entry) */
 
 /* activation codes (TE:124-134) */
 #define SCN_ACT_NONE        0
@@ -328,7 +329,9 @@ int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, 
  * of a SQUARE operator (pattern as for scn_plan_refine_order; val1, nnz floats or NULL, marks the second operator's entries;
  * block_start as for scn_conv_create_blocked or NULL).  out4[0] = lane-group reads (one per quad of rows and entry position),
  * out4[1] = their LDS cycles with the sources in row order and the entries in CSR order, out4[2] = with the plan's layout
- * (slot colours + entry order, csrc/scn_blk_layout.inc; out4[2] == out4[0] means no bank conflict is left), out4[3] = blocks. */
+ * (slot colours + entry order, csrc/scn_blk_layout.inc; out4[2] == out4[0] means no bank conflict is left), out4[3] = blocks.
+ * Every block's layout is also CHECKED: each row's entries placed exactly once inside its quad's width, second-operator entries
+ * inside the leading positions, slots a permutation of the sources -- SCN_ERR_INTERNAL otherwise. */
 int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val1, int32_t identity,
                           const uint8_t* block_start, int64_t* out4);
 

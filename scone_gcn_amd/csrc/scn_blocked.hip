@@ -123,6 +123,7 @@ extern "C" int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int
         for (int mode = 0; mode < 2; ++mode) {
             scn::layout_input(L, rowptr, col, val1, identity != 0, r0, rows, w, (int)cur.size(), local);
             scn::layout_block(L, mode == 1);
+            if (!scn::layout_valid(L)) return SCN_ERR_INTERNAL;
             out4[1 + mode] += L.cycles;
         }
         out4[0] += L.positions;

@@ -293,6 +293,7 @@ const char* scn_error_string(int status) {
         case SCN_ERR_UNSUPPORTED: return "unsupported configuration";
         case SCN_ERR_NOMEM: return "out of memory";
         case SCN_ERR_WORKSPACE: return "workspace too small";
+        case SCN_ERR_INTERNAL: return "internal self-check failed";
         default: return "unknown status";
     }
 }
