@@ -121,6 +121,28 @@ def test_block_layout_removes_most_lds_bank_conflicts_of_the_gather(cx):
     assert lib.scn_plan_gather_stats(pat.shape[0], as_p(rowptr), as_p(bad), None, 1, None, out.ctypes.data) != 0
 
 
+def test_refine_order_deals_the_sorted_row_groups_evenly_to_the_simds():
+    """scn_plan_refine_order: inside a block the rows are sorted by entry count, and the eight 8-row groups then go in the order
+    (width ranks) 3 2 1 0 4 5 6 7, so that the two groups a SIMD hosts (wave i on SIMD i mod 4) pair widest with narrowest."""
+    import ctypes
+    from scone_gcn_amd import _lib
+    n = 64                                               # one block (64 rows x <= 16 entries fit its ELL tile): row i has 2 + (i * 7) % 15 entries
+    rows = [sorted({(i + 1 + 3 * k) % n for k in range(2 + (i * 7) % 15)} - {i}) for i in range(n)]
+    rowptr = np.zeros(n + 1, np.int32)
+    rowptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.int32)
+    order, starts = np.empty(n, np.int32), np.zeros(n, np.uint8)
+    as_p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    _lib.check(_lib.load().scn_plan_refine_order(n, as_p(rowptr), as_p(col), 1, as_p(order), starts.ctypes.data), "refine")
+    assert np.array_equal(np.sort(order), np.arange(n)) and starts[0] == 1 and starts[1:].sum() == 0
+    width = np.diff(rowptr)[order].reshape(8, 8)
+    assert all((np.diff(g) <= 0).all() for g in width)   # rows sorted inside every group
+    gmax = width.max(axis=1)
+    assert list(np.argsort(-gmax, kind="stable")) == [3, 2, 1, 0, 4, 5, 6, 7]
+    pair = gmax[:4] + gmax[4:]                            # what the SIMDs of the 8-wave kernels carry
+    assert pair.max() - pair.min() <= (gmax.max() - gmax.min()) // 2 + 2
+
+
 def test_hilbert_index_is_a_bijection_on_a_grid():
     xs, ys = np.meshgrid(np.arange(16), np.arange(16))
     d = hilbert_index(xs.ravel(), ys.ravel(), order=4)
