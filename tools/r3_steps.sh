@@ -33,9 +33,6 @@ for s in "$@"; do
                  step ff_base 300 python3 tools/prof_kernels.py --which fwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor1.so step ff_floor1 300 python3 tools/prof_kernels.py --which fwd --reps 3
                  SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_ffloor2.so step ff_floor2 300 python3 tools/prof_kernels.py --which fwd --reps 3 ;;
-    ab_noconf)   step ab_base 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_noconf.so step ab_noconf 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
-                 SCN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/lib_noconf.so step pmc_noconf 300 bash tools/pmc_run.sh $OUT/pmc_noconf sq2 tools/prof_kernels.py --which fwd,bwd --reps 2 ;;
     layout_check) step tests_quick 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu
                  step ab_new 200 python3 tools/prof_kernels.py --which fwd,bwd --reps 4
                  step bq_new 400 python3 bench.py --extras 0 --steps 5 --warmup 1
