@@ -15,9 +15,14 @@ that is already resident in HBM: forward, loss, backward, RCCL all-reduce of the
 ridge + Adam.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line (N = 1 only, unless noted):
-  roofline      the kernel family that takes the most time in the step, timed live with events on the launch stream:
-                algorithmic bytes per launch / mean launch duration vs the 8 TB/s HBM peak; `dense_random` repeats the
-                two fused C=32 kernels on dense random tensors (the benchmark's activations are mostly exact zeros).
+  roofline      the kernel FAMILY (template variants summed: the plain and the fused-first backward are one family) that takes
+                the most time in the step, timed live with events on the launch stream: algorithmic bytes of its launches /
+                their duration vs the 8 TB/s HBM peak, every variant's own fraction in `variants`; `traffic` = HBM bytes per
+                launch from the committed rocprofv3 --pmc passes, cited only while the kernel sources are the ones the passes
+                ran on; `spmm_dual_*` = the SpMM half of the metric (dense random X); `dense_random_*` repeats the two fused
+                C=32 kernels on dense random tensors (the benchmark's activations are mostly exact zeros).
+  validation    (every N) loss of the batch after the steps, summed over ranks, and the replicas' weights against rank 0's:
+                the global batch is drawn once with seed 1030 on every rank and sharded by index, so N = 1 and N > 1 agree.
   cpu_baseline  the reference formulation on this box's host cores: B2 = fp32 torch.sparse_csr forward + autograd
                 backward on a bounded sample of the SAME workload (oracle/torch_sparse.py), B1 = the dense-faithful fp32
                 torch restatement (dense shifts, full-N forward then mask, autograd, Adam; oracle/torch_dense.py) on
@@ -109,7 +114,7 @@ def cpu_baseline_sparse(cx, sc, flows, choice, last, hidden, n_sample):
     for _ in range(passes):
         ts.loss_and_grad(w, Sl, Su, Sl, Su, rows, last[sel], X, y, 5e-5)
     dt = (time.perf_counter() - t0) / passes
-    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(torch.get_num_threads()), "kind": "restatement",
+    return {"value": n_sample / dt, "unit": "trajectories/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "dtype": "f32", "host_cpus": os.cpu_count(),
             "sample": "%d trajectories of the same |E|=%d complex, hidden %d: this repo's CPU restatement of the reference "
                       "formulation (TE:137-152, STM:42-56; oracle/torch_sparse.py -- the reference's JAX code cannot run here) "
@@ -207,36 +212,77 @@ def time_config(net, inputs, staged, total, steps, warmup, sync, all_max):
     return dt, kt.table()
 
 
+def family(key):
+    """Timer key -> kernel family: the template variants of one kernel (the fused-first backward `+ dW_first`, the
+    `(dW only)` form) are one family; different kernels (first layer c1->C vs the fused C->C) are not."""
+    return key.replace(" + dW_first", "").replace(" (dW only)", "")
+
+
 def dominant(table):
-    """(key, row) of the kernel family with the largest launches x mean time among those with a byte model."""
-    rows = {k: r for k, r in table.items() if r["alg_bytes"]}
-    if not rows:
+    """(family, [keys]) of the kernel family with the largest sum of launches x mean time among those with a byte model."""
+    fams = {}
+    for k, r in table.items():
+        if r["alg_bytes"]:
+            fams.setdefault(family(k), []).append(k)
+    if not fams:
         return None, None
-    k = max(rows, key=lambda k: rows[k]["launches"] * rows[k]["avg_ms"])
-    return k, rows[k]
+    f = max(fams, key=lambda f: sum(table[k]["launches"] * table[k]["avg_ms"] for k in fams[f]))
+    return f, sorted(fams[f])
 
 
 def roofline_of(table, units_per_launch):
-    k, r = dominant(table)
-    if k is None:
+    """The dominant kernel FAMILY of the timed step: achieved = algorithmic bytes of all its launches / their summed duration
+    (HIP events on the launch stream, ops.KernelTimer); every template variant's own fraction beside it."""
+    fam, keys = dominant(table)
+    if fam is None:
         return None
-    ach = r["alg_bytes"] / (r["avg_ms"] * 1e-3)
-    return {"bound": "hbm", "kernel": k, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-            "traffic": None, "launch_ms": r["avg_ms"], "launches_per_step": r["launches"],
-            "algorithmic_bytes_per_launch": r["alg_bytes"], "units_per_launch": units_per_launch}
+    n = sum(table[k]["launches"] for k in keys)
+    ms = sum(table[k]["launches"] * table[k]["avg_ms"] for k in keys)
+    nb = sum(table[k]["launches"] * table[k]["alg_bytes"] for k in keys)
+    step_ms = sum(r["launches"] * r["avg_ms"] for r in table.values())
+    ach = nb / (ms * 1e-3)
+    out = {"bound": "hbm", "kernel": fam, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+           "traffic": None, "launch_ms": ms / n, "launches_per_step": n, "algorithmic_bytes_per_launch": nb / n,
+           "units_per_launch": units_per_launch, "share_of_step_kernel_time": ms / step_ms if step_ms else None,
+           "variants": {k: {"launches": table[k]["launches"], "launch_ms": table[k]["avg_ms"],
+                            "algorithmic_bytes_per_launch": table[k]["alg_bytes"],
+                            "frac": table[k]["alg_bytes"] / (table[k]["avg_ms"] * 1e-3) / HBM_PEAK} for k in keys}}
+    for i, k in enumerate(keys):                        # flat copies: a parser that drops nested objects still sees them
+        out["variant%d" % i] = "%s: %.3f of peak, %.3f ms x %d" % (k, out["variants"][k]["frac"], table[k]["avg_ms"], table[k]["launches"])
+    return out
 
 
-def measured_traffic(section, kernel_key):
-    """HBM bytes per launch of a timed kernel family from the committed rocprofv3 --pmc passes (profiles/r03_pmc_traffic.json:
-    2 * FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM; dense random tensors of the same launch shape)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    sec = json.load(open(path)).get(section, {})
+def traffic_file():
+    """The newest committed profiles/rNN_pmc_traffic.json (rocprofv3 --pmc passes merged by tools/pmc_merge.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
+def measured_traffic(section, keys):
+    """(HBM bytes per launch, source) of a timed kernel family from the committed rocprofv3 --pmc passes: 2 * FETCH_SIZE +
+    WRITE_SIZE (MI355X_MICROARCH.md section HBM), launch-weighted over the family's variants.  The file carries the hash of the
+    kernel sources it was measured on (scone_gcn_amd._lib.sources_sha); when the checkout's differs the bytes are NOT cited."""
+    from scone_gcn_amd import _lib
+    path = traffic_file()
+    if path is None:
+        return None, "no profiles/rNN_pmc_traffic.json"
+    doc = json.load(open(path))
+    rel = os.path.relpath(path, ROOT)
+    if doc.get("kernel_sources_sha") != _lib.sources_sha():
+        return None, "%s was measured on other kernel sources (%s, checkout %s): not cited" % (
+            rel, str(doc.get("kernel_sources_sha"))[:12], _lib.sources_sha()[:12])
+    sec = doc.get(section, {})
+    tot = n = 0.0
+    names = []
     for name, row in sec.get("kernels", {}).items():
-        if kernel_key in row.get("timer_keys", []):
-            return row.get("hbm_bytes_per_launch"), "profiles/r03_pmc_traffic.json [%s] %s (%s)" % (section, name, sec.get("launch", ""))
-    return None, None
+        if set(row.get("timer_keys", [])) & set(keys) and row.get("hbm_bytes_per_launch"):
+            tot += row["hbm_bytes_per_launch"] * row.get("launches_seen", 1)
+            n += row.get("launches_seen", 1)
+            names.append(name)
+    if not n:
+        return None, "%s [%s] has no row for %s" % (rel, section, keys)
+    return tot / n, "%s [%s] %s (%s)" % (rel, section, ", ".join(names), sec.get("launch", ""))
 
 
 def slim(table):
@@ -283,9 +329,7 @@ def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data
     if layers:
         out["hidden_layers"] = [list(l) for l in layers]
     if out["roofline"] and traffic_section:
-        out["roofline"]["traffic"], src = measured_traffic(traffic_section, out["roofline"]["kernel"])
-        if src:
-            out["roofline"]["traffic_source"] = src
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(traffic_section, list(out["roofline"]["variants"]))
     out["graph_replayed_step"] = bool(net._graphs)
     alg = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
     out["step_model"] = {"kernel_algorithmic_bytes_per_trajectory": alg / batch,
@@ -341,7 +385,14 @@ def main():
     t_setup = time.perf_counter()
     cx = g.random_SC_graph(g.calibrate_n_points(args.edges))
     sc = SimplicialComplex(cx)
-    flows, choice, last, y = dataset(cx, sc, B, 1030 + rank)
+    # the GLOBAL batch is drawn ONCE with a fixed seed -- every rank draws the same `total` trajectories -- and
+    # sharded by index (distributed.shard_indices, exactly as Scone_GCN.grad_step shards a masked batch): the batch, hence the
+    # loss and the weights after K steps, do not depend on the rank count (up to the summation order of the all-reduce).
+    flows_all, choice_all, last_all, y_all = dataset(cx, sc, total, 1030)
+    mine = dp.shard_indices(np.arange(total), rank, world)
+    assert len(mine) == B
+    flows, choice, last, y = flows_all.select(mine), choice_all[mine], last_all[mine], y_all[mine]
+    del flows_all, y_all
     net, inputs = make_net("scone", args.hidden, sc, flows, last, y, B)
     staged = net.stage(inputs, y, np.arange(B))
     plan = net._plan(inputs)
@@ -353,21 +404,52 @@ def main():
     dt, table = time_config(net, inputs, staged, total, args.steps, args.warmup, sync, all_max)
     value = total * args.steps / dt
     roofline = roofline_of(table, mb)
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes (same |E|, hidden and launch size only)
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (same |E|, hidden and launch size only; dropped when the
+    # kernel sources have changed since the passes were taken)
     if roofline and E == 996634 and mb == 128 and C == 32:
         for section in ("main_bench", "main"):          # on the benchmark's own trajectories (what launch_ms is measured on), else dense random
-            t, src = measured_traffic(section, roofline["kernel"])
-            if t:
-                roofline["traffic"], roofline["traffic_source"] = t, src
+            roofline["traffic"], roofline["traffic_source"] = measured_traffic(section, list(roofline["variants"]))
+            if roofline["traffic"]:
                 break
+    # ---- self-validation of the data-parallel step (every N): the loss of one more step on the same batch, summed over the
+    # ranks, and the replicas' weights against rank 0's (identical Adam on identical reduced gradients => bitwise equal)
+    part = net.grad_step_staged(inputs, staged, total, apply=False)        # this rank's share of the data term, weights untouched
+    red_dev = "cuda" if (world == 1 or args.backend == "nccl") else "cpu"
+    loss_t = part.detach().double().reshape(1).to(red_dev)
+    w0 = net._flat_w.detach().clone().to(red_dev)
+    if world > 1:
+        dist.all_reduce(loss_t, op=dist.ReduceOp.SUM)
+        dist.broadcast(w0, src=0)
+    dev_w = (net._flat_w.detach().to(red_dev) - w0).abs().max().double().reshape(1)
+    if world > 1:
+        dist.all_reduce(dev_w, op=dist.ReduceOp.MAX)
+    wf = net._flat_w.detach().double()
+    validation = {"loss": float(loss_t.item()), "replicas_identical": bool(float(dev_w.item()) == 0.0),
+                  "max_abs_weight_deviation_from_rank0": float(dev_w.item()),
+                  "weights_sum": float(wf.sum().item()), "weights_l2": float(wf.norm().item()),
+                  "optimiser_steps_taken": args.steps + args.warmup,
+                  "note": "loss = batch cross-entropy (data term, STM:54) after the warm-up and timed steps, summed over ranks; the global "
+                          "batch is seed-1030's for every N, so N = 1 and N > 1 lines agree to summation order"}
+
     alg_step = sum(r["alg_bytes"] * r["launches"] for r in table.values() if r["alg_bytes"])
     survey_bytes = 4.0 * E * (15 * C + 2)
     step_model = {"survey_model_bytes_per_trajectory": survey_bytes,
-                  "survey_model_frac_of_hbm_peak_whole_step": value / world * survey_bytes / HBM_PEAK,
+                  "survey_model_bytes_rate_not_achieved_bandwidth_frac_of_hbm_peak": value / world * survey_bytes / HBM_PEAK,
                   "kernel_algorithmic_bytes_per_trajectory": alg_step / B,
                   "kernel_model_frac_of_hbm_peak_whole_step": value / world * (alg_step / B) / HBM_PEAK,
-                  "note": "survey model = SURVEY.md section 8d (4*E*(15*C+2): every activation tensor once per pass); kernel model "
-                          "= sum of the timed kernels' own algorithmic bytes (what `roofline` and `kernels` price)"}
+                  "note": "survey model = SURVEY.md section 8d (4*E*(15*C+2): every activation tensor once per pass) -- the fused "
+                          "kernels move FEWER bytes than that model, so its rate is a model-bytes rate, not achieved bandwidth; "
+                          "kernel model = sum of the timed kernels' own algorithmic bytes (what `roofline` and `kernels` price)"}
+    collective = None
+    if world > 1:
+        ver = ""
+        if args.backend == "nccl":
+            try:
+                ver = " (RCCL %s)" % ".".join(map(str, torch.cuda.nccl.version()))
+            except Exception as e:                          # version query only; the collective itself has already run
+                ver = " (RCCL version query failed: %s)" % type(e).__name__
+        collective = "%s%s, dist.get_world_size() = %d: one all-reduce (sum) of %d fp32 weight gradients per step" % (
+            dist.get_backend(), ver, dist.get_world_size(), net._flat_g.numel())
 
     line = {
         "metric": "trajectories/sec fwd+bwd, 3-layer SCoNe |E|~1M batch=%d; SpMM HBM GB/s" % total, "value": value,
@@ -379,10 +461,10 @@ def main():
                                % (E, cx.n_nodes, cx.n_faces, C, total, B, world, mb),
                    "edges": E, "nodes": cx.n_nodes, "faces": cx.n_faces, "hidden": C, "global_batch": total,
                    "per_gpu_batch": B, "micro_batch": mb, "parallelism": "dp%d" % world,
-                   "collective": ("%s all-reduce of %d fp32 weight gradients per step" % (args.backend, net._flat_g.numel()))
-                   if world > 1 else None,
+                   "collective": collective, "batch_seed": 1030,
                    "nnz_lower": plan.nnz_lower, "nnz_upper": plan.nnz_upper, "nnz_pattern": plan.nnz_pattern},
-        "roofline": roofline, "cpu_baseline": None, "step_model": step_model, "kernels": slim(table), "setup_s": t_setup,
+        "roofline": roofline, "cpu_baseline": None, "replicas_identical": validation["replicas_identical"],
+        "loss": validation["loss"], "validation": validation, "step_model": step_model, "kernels": slim(table), "setup_s": t_setup,
     }
 
     # ---- weak-scaling companion: 512 trajectories per GPU (every N), + the zero-skipping modes on the same batch
@@ -412,13 +494,15 @@ def main():
                               "active_fraction_of_block_slab_items": {k: [round(v, 4) for v in af[k]] for k in af},
                               "note": "same step, same results; work items whose values are exactly zero"
                                       + (" or that the loss cannot see" if mode == "field" else "") + " are not computed"}
-            tf = os.path.join(ROOT, "profiles", "r03_skip_traffic.json")    # rocprofv3 --pmc passes of tools/pmc_skip.sh (round-3 kernels)
-            if os.path.exists(tf) and E == 996634 and C == 32:
+            import glob
+            tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_skip_traffic.json")))   # rocprofv3 --pmc passes of tools/pmc_skip.sh
+            if tfs and E == 996634 and C == 32:
+                tf = tfs[-1]
                 meas = json.load(open(tf))
                 skipping[mode]["hbm_bytes_per_trajectory"] = {
                     "dense_model": survey_bytes, "measured_dense": meas["dense"]["hbm_bytes_per_trajectory"],
                     "measured_this_mode": meas[mode]["hbm_bytes_per_trajectory"],
-                    "source": "profiles/r03_skip_traffic.json (2*FETCH_SIZE+WRITE_SIZE, steady state)"}
+                    "source": "%s (2*FETCH_SIZE+WRITE_SIZE, steady state; measured in the round the file names)" % os.path.relpath(tf, ROOT)}
             del st_m
         if skipping:
             line["zero_skipping"] = skipping
@@ -449,8 +533,18 @@ def main():
             for _ in range(5):
                 plan.conv.spmm_dual(xr.view(S, E, 4 * C))
         (_, r2), = kt2.table().items()
-        line["spmm_dual"] = {"GB/s": r2["GB/s"], "frac_of_8TBps": r2["GB/s"] * 1e9 / HBM_PEAK, "ms": r2["avg_ms"],
-                             "algorithmic_bytes": r2["alg_bytes"], "x": "[%d, %d, %d] dense random fp32" % (S, E, 4 * C)}
+        sp = {"GB/s": r2["GB/s"], "frac_of_8TBps": r2["GB/s"] * 1e9 / HBM_PEAK, "ms": r2["avg_ms"],
+              "algorithmic_bytes": r2["alg_bytes"], "x": "[%d, %d, %d] dense random fp32" % (S, E, 4 * C)}
+        if E == 996634 and C == 32:
+            sp["traffic"], sp["traffic_source"] = measured_traffic("main", ["spmm_dual k%d" % (4 * C)])
+        line["spmm_dual"] = sp
+        if roofline:                                      # the SpMM half of BASELINE's metric, inside `roofline` (flat scalars)
+            roofline["spmm_dual_frac"] = sp["frac_of_8TBps"]
+            roofline["spmm_dual_GBps"] = sp["GB/s"]
+            roofline["spmm_dual_ms"] = sp["ms"]
+            roofline["spmm_dual_algorithmic_bytes"] = sp["algorithmic_bytes"]
+            roofline["spmm_dual_traffic"] = sp.get("traffic")
+            roofline["spmm_dual_x"] = sp["x"]
         if C == 32:
             Wr = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
             aux = torch.tanh(torch.randn((S, E, 4, C), device="cuda"))
@@ -463,8 +557,12 @@ def main():
                     plan.conv.backward([xr], Wr, aux, "tanh", True, dWs)
             dense_random = {k: {"ms": r["avg_ms"], "GB/s": r["GB/s"], "frac": r["GB/s"] * 1e9 / HBM_PEAK}
                             for k, r in kt3.table().items()}
-            if line["roofline"]:
-                line["roofline"]["dense_random"] = dense_random
+            if roofline:
+                roofline["dense_random"] = dense_random
+                for k, r in dense_random.items():         # flat copies
+                    tag = "fwd" if k.startswith("conv_fwd") else "bwd"
+                    roofline["dense_random_%s_frac" % tag] = r["frac"]
+                    roofline["dense_random_%s_ms" % tag] = r["ms"]
             del Wr, aux, dWs
         del xr
         torch.cuda.empty_cache()

@@ -221,11 +221,11 @@ class Adam:
 
 def _apply_shift(S, H):
     """S @ H for every sample: S (R, E) dense ndarray or scipy sparse; H (N, E, C) -> (N, R, C)."""
-    if hasattr(S, "tocsr"):                       # scipy sparse: fold the batch into columns
-        N, E, C = H.shape
-        Y = S @ H.transpose(1, 0, 2).reshape(E, N * C)
-        return np.ascontiguousarray(Y.reshape(S.shape[0], N, C).transpose(1, 0, 2))
-    return np.einsum("re,nec->nrc", S, H)
+    # dense or scipy sparse alike: fold the batch into columns, ONE (R, E) x (E, N*C) product (BLAS / CSR SpMM) --
+    # the sums of `S @ H[n]` per sample (TE:146-147) in fp64; an un-optimised einsum spent minutes of the GPU suite here
+    N, E, C = H.shape
+    Y = S @ H.transpose(1, 0, 2).reshape(E, N * C)
+    return np.ascontiguousarray(np.asarray(Y).reshape(S.shape[0], N, C).transpose(1, 0, 2))
 
 
 def conv_forward(weights, S_lower, S_upper, flow, act="tanh", keep=False):

@@ -162,3 +162,16 @@ def i32_array(vals):
     for i, v in enumerate(vals):
         arr[i] = int(v)
     return arr
+
+
+def sources_sha():
+    """SHA-256 over the kernel sources (csrc/*.hip, *.inc, *.h, in name order): the stamp a committed counter profile carries
+    (tools/pmc_merge.py) and bench.py compares before citing measured HBM bytes for a kernel."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()

@@ -338,3 +338,32 @@ def test_exact_split_bf16_kernels_hold_fp32_accuracy_on_wide_dynamic_range():
             refw = np.einsum("srnc,srnd->cd", aux, gk[k])
             sw = np.einsum("srnc,srnd->cd", np.abs(aux), ga[k])
             assert (np.abs(dWs[k].cpu().numpy() - refw) / sw).max() <= 1e-4, (C, k)   # fp32 accumulation over S*E*4 = 1e5 terms
+
+
+def test_bench_lines_of_one_and_two_ranks_agree_on_loss_and_weights():
+    """bench.py is self-validating across rank counts (the host draws the batch once, shards by index; STM:256's
+    batch axis, STM:313-322's mask semantics): `--gpus 1` and `--gpus 2 --backend gloo` (both ranks on this one GPU, the
+    gradient all-reduce through gloo) on the same complex take the same optimiser steps -- equal loss and weights to the
+    summation order of the reduction -- and the two replicas hold bitwise identical weights."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--extras", "0",
+               "--edges", "50000", "--hidden", "16", "--global-batch", "64", "--steps", "3", "--warmup", "1"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = lines[1], lines[2]
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["config"]["per_gpu_batch"] == 32
+    assert a["replicas_identical"] is True and b["replicas_identical"] is True
+    assert "world_size() = 2" in b["config"]["collective"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * max(1.0, abs(a["loss"]))
+    va, vb = a["validation"], b["validation"]
+    assert abs(va["weights_sum"] - vb["weights_sum"]) <= 1e-6 * max(1.0, abs(va["weights_sum"]))
+    assert abs(va["weights_l2"] - vb["weights_l2"]) <= 1e-6 * va["weights_l2"]

@@ -145,3 +145,85 @@ def test_mixed_width_stacks_at_one_million_edges(big_complex, layers):
         times[name] = (time.perf_counter() - t0) / 3
     print("step time mixed %.2f ms, uniform hidden 32 %.2f ms" % (times["mixed"] * 1e3, times["uniform32"] * 1e3))
     assert times["mixed"] <= 2.0 * times["uniform32"]
+
+
+@pytest.fixture(scope="module")
+def cfg2_complex():
+    """BASELINE configs[1]'s complex: the reference generator's recipe calibrated to |E| ~ 50 k."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(g.calibrate_n_points(50_000))
+    assert abs(cx.n_edges - 50_000) < 1_000
+    return cx, SimplicialComplex(cx)
+
+
+def test_configs1_workload_one_launch_of_1024_trajectories_against_the_csr_oracle(cfg2_complex):
+    """BASELINE configs[1] AT ITS OWN WORKLOAD: |E| ~ 50 k, hidden 16, batch 1024 as ONE micro-batch -- the launch shape
+    bench.py times there (~830 plan blocks x 256 slabs on the slab-pair kernels, blocks x slabs split over the grid).
+    TE:137-152 + STM:42-56 through `grad_step_staged(apply=False)`:
+    (1) log-probabilities of that launch for 32 trajectories spread over the whole slab range, and the loss + all ten weight
+        gradients of the 1024-trajectory launch when exactly those 32 carry a target (the loss is linear in the targets: the
+        other 992 trajectories run through every kernel and contribute exact zeros), against the fp64 scipy-CSR oracle on the 32;
+    (2) all 1024 targets live: the same launch against four launches of 256 (another grid split; equal to summation order)
+        and against the exact zero-skipping work lists on the full batch (same loss and gradients)."""
+    import scipy.sparse as sp
+    from scone_gcn_amd import ops, scone_trajectory_model as stm, synthetic_data_gen as g, trajectory_experiments as te
+    cx, sc = cfg2_complex
+    N, hidden, n_chk = 1024, 16, 32
+    flows, last, y = _dataset(cx, sc, N, 57)
+    w = _weights(so.weight_shapes(1, [(3, hidden)] * 3, 1), 0.12, 11)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-3, N, 0.0, verbose=False)
+    net.setup(te.scone_func, [(3, hidden)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+    for a, b in zip(net.weights, w):
+        a.copy_(torch.as_tensor(b, dtype=torch.float32))
+    w64 = [a.detach().cpu().numpy().astype(np.float64) for a in net.weights]
+
+    # (1) 32 trajectories spread over the 256 slabs carry the targets
+    rs = np.random.RandomState(3)
+    chk = np.sort(rs.choice(N, n_chk, replace=False))
+    y_chk = np.zeros_like(y)
+    y_chk[chk] = y[chk]
+    staged = net.stage(inputs, y_chk, np.arange(N))
+    assert len(staged) == 1 and staged[0][0].shape[0] * ops.NS == N, "configs[1] must run as one micro-batch of 1024"
+    loss = float(net.grad_step_staged(inputs, staged, n_chk, apply=False))
+    grads = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+    B1, B2 = g.incidence_matrices(cx)
+    L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+    B1x = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()
+    Bc = lambda n: B1x[sc.nbrhoods[n]].toarray()
+    Xc = flows.select(chk).todense().astype(np.float64)
+    ref_loss, ref_g = so.scone_loss_and_grad(w64, L_lo, L_up, Bc, last[chk], Xc, y[chk], np.ones(n_chk, int), 0.0)
+    _check(loss, grads, ref_loss, ref_g, "configs[1]: one launch of %d trajectories, %d of them with targets, |E| = %d"
+           % (N, n_chk, cx.n_edges))
+    ref_logp = so.scone_forward(w64, L_lo, L_up, Bc, last[chk], Xc)
+    logp = te.scone_func(net.weights, *shifts, readout, last, flows).cpu().numpy().astype(np.float64)
+    assert logp.shape == (N, sc.max_degree, 1)
+    assert np.abs(logp[chk] - ref_logp).max() <= TOL * max(1.0, np.abs(ref_logp).max())
+
+    # (2) every target live: one launch of 1024 == four launches of 256 == the exact zero-skipping work lists
+    staged = net.stage(inputs, y, np.arange(N))
+    loss_1 = float(net.grad_step_staged(inputs, staged, N, apply=False))
+    g_1 = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+    del staged
+    loss_4, g_4 = 0.0, [np.zeros_like(a) for a in g_1]
+    for c0 in range(0, N, 256):
+        st = net.stage(inputs, y, np.arange(c0, c0 + 256))
+        assert len(st) == 1
+        loss_4 += float(net.grad_step_staged(inputs, st, N, apply=False))
+        for a, t in zip(g_4, net._grads):
+            a += t.detach().cpu().numpy().astype(np.float64)
+        del st
+    gmax = max(float(np.abs(a).max()) for a in g_1)
+    assert abs(loss_1 - loss_4) <= 1e-6 * max(1.0, abs(loss_1))
+    assert max(float(np.abs(a - b).max()) for a, b in zip(g_1, g_4)) <= 2e-6 * gmax
+    st_z = net.stage(inputs, y, np.arange(N), skip="zeros")
+    assert len(st_z) == 1 and st_z[0][3] is not None
+    loss_z = float(net.grad_step_staged(inputs, st_z, N, apply=False))
+    g_z = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+    assert abs(loss_z - loss_1) <= 1e-6 * max(1.0, abs(loss_1))
+    assert max(float(np.abs(a - b).max()) for a, b in zip(g_z, g_1)) <= 2e-6 * gmax

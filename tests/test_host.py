@@ -409,3 +409,38 @@ def test_hidden_width_promotion_pads_and_cuts_back():
     gp = [torch.full_like(t, 2.0) if t is not t0 else g0 for t, t0, g0 in zip(wp, w, g)]
     ops.demote_grads(g, gp)
     assert all(float(g[i].sum()) == 0.0 for i in range(3)) and all(bool((g[i] == 2.0).all()) for i in range(3, 7))
+
+
+def test_bench_roofline_is_per_kernel_family_and_cites_traffic_only_for_the_measured_sources(tmp_path, monkeypatch):
+    """bench.py's bookkeeping (no GPU): the dominant kernel is picked per FAMILY (the plain and the fused-first backward are
+    one template), every variant keeps its own fraction, and committed PMC traffic is cited only while the kernel sources
+    hash to what the profile was measured on."""
+    import json
+    import bench
+    from scone_gcn_amd import _lib
+    table = {"conv_fwd c32->32": {"launches": 64, "avg_ms": 8.0, "alg_bytes": 32.8e9, "GB/s": 4100.0},
+             "conv_bwd c32->32": {"launches": 32, "avg_ms": 11.7, "alg_bytes": 49.0e9, "GB/s": 4188.0},
+             "conv_bwd c32->32 + dW_first": {"launches": 32, "avg_ms": 11.2, "alg_bytes": 34.7e9, "GB/s": 3098.0},
+             "conv_fwd c1->32": {"launches": 32, "avg_ms": 3.1, "alg_bytes": 16.9e9, "GB/s": 5450.0},
+             "readout": {"launches": 32, "avg_ms": 0.1, "alg_bytes": None, "GB/s": None}}
+    r = bench.roofline_of(table, 128)
+    assert r["kernel"] == "conv_bwd c32->32" and r["launches_per_step"] == 64
+    assert set(r["variants"]) == {"conv_bwd c32->32", "conv_bwd c32->32 + dW_first"}
+    want = (32 * 49.0e9 + 32 * 34.7e9) / ((32 * 11.7 + 32 * 11.2) * 1e-3) / 8.0e12
+    assert abs(r["frac"] - want) < 1e-12
+    assert abs(r["variants"]["conv_bwd c32->32 + dW_first"]["frac"] - 34.7e9 / 11.2e-3 / 8.0e12) < 1e-12
+    assert 0.5 < r["share_of_step_kernel_time"] < 0.6
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    doc = {"main_bench": {"launch": "test", "kernels": {
+        "scn::bwd<a>": {"hbm_bytes_per_launch": 55.0e9, "launches_seen": 8, "timer_keys": ["conv_bwd c32->32"]},
+        "scn::bwd<b>": {"hbm_bytes_per_launch": 42.0e9, "launches_seen": 8, "timer_keys": ["conv_bwd c32->32 + dW_first"]}}},
+        "kernel_sources_sha": "stale"}
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, src = bench.measured_traffic("main_bench", list(r["variants"]))
+    assert t is None and "not cited" in src
+    doc["kernel_sources_sha"] = _lib.sources_sha()
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps(doc))
+    t, src = bench.measured_traffic("main_bench", list(r["variants"]))
+    assert t == 48.5e9 and "r09_pmc_traffic.json" in src

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Merge tools/pmc_run.sh outputs into profiles/r03_pmc_traffic.json, keyed the way bench.py looks traffic up:
+"""Merge tools/pmc_run.sh outputs into profiles/rNN_pmc_traffic.json, keyed the way bench.py looks traffic up (and stamped
+with the hash of the kernel sources the passes ran on: bench.py cites the bytes only while the checkout's hash is the same):
     python tools/pmc_merge.py out.json  main=<dir>/pmc.json:"launch text"  "configs[1]"=...  ebli=...  bunch=...
 Every kernel row gets `timer_keys`: the ops.KernelTimer families it runs under."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scone_gcn_amd import _lib
 
 
 def timer_keys(name):
@@ -44,5 +49,6 @@ for spec in sys.argv[2:]:
 res["note"] = ("rocprofv3 --pmc passes (tools/pmc_run.sh: FETCH_SIZE, WRITE_SIZE, TCC hit/miss in separate runs), mean per launch; "
                "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KB: gfx950 reports half of wide coalesced reads "
                "(MI355X_MICROARCH.md, section HBM)")
+res["kernel_sources_sha"] = _lib.sources_sha()
 json.dump(res, open(out, "w"), indent=1)
 print("wrote", out, {s: list(v["kernels"]) for s, v in res.items() if isinstance(v, dict)})
