@@ -37,11 +37,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---- diagnostic build only (-DSCN_STAMPS): per-segment cycle sums of fwd_c32, never compiled into the product
 #ifdef SCN_STAMPS
 __device__ unsigned long long g_stamps[8];
+// per wave INDEX of the workgroup (summed over workgroups): [0..5] the segment sums, [6] sum of skew^2 / 1024 (segment 1 = the slab
+// barrier), [7] barrier intervals, [8] sum of the SIMD id the wave ran on (HW_REG_HW_ID bits 5:4), [9] waves
+__device__ unsigned long long g_stamps_w[16][10];
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_DECL unsigned long long t0_ = 0, t1_ = 0, acc_[6] = {0, 0, 0, 0, 0, 0}
-#define STAMP_ADD(i) do { STAMP(t1_); acc_[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#define STAMP_DECL unsigned long long t0_ = 0, t1_ = 0, acc_[6] = {0, 0, 0, 0, 0, 0}, sq_ = 0, nint_ = 0
+#define STAMP_ADD(i) do { STAMP(t1_); acc_[i] += t1_ - t0_; if ((i) == 1) { sq_ += ((t1_ - t0_) * (t1_ - t0_)) >> 10; ++nint_; } t0_ = t1_; } while (0)
 #define STAMP_START() STAMP(t0_)
-#define STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long s_ = 0; for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_stamps[i_], acc_[i_]); s_ += acc_[i_]; } atomicMax(&g_stamps[6], s_); atomicAdd(&g_stamps[7], 1ull); } } while (0)
+#define STAMP_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long s_ = 0; const int w_ = (threadIdx.x >> 6) & 15; \
+    for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_stamps[i_], acc_[i_]); atomicAdd(&g_stamps_w[w_][i_], acc_[i_]); s_ += acc_[i_]; } \
+    atomicMax(&g_stamps[6], s_); atomicAdd(&g_stamps[7], 1ull); atomicAdd(&g_stamps_w[w_][6], sq_); atomicAdd(&g_stamps_w[w_][7], nint_); \
+    atomicAdd(&g_stamps_w[w_][8], (unsigned long long)((__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | ((2 - 1) << 11))) & 3)); \
+    atomicAdd(&g_stamps_w[w_][9], 1ull); } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_ADD(i)
@@ -137,6 +144,11 @@ extern "C" int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int
 extern "C" int scn_debug_stamps(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(scn::g_stamps), 64) != hipSuccess) return -3;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(scn::g_stamps), z, 64) != hipSuccess) return -3; }
+    return 0;
+}
+extern "C" int scn_debug_stamps_waves(unsigned long long* out160, int reset) {
+    if (hipMemcpyFromSymbol(out160, HIP_SYMBOL(scn::g_stamps_w), 1280) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[160] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(scn::g_stamps_w), z, 1280) != hipSuccess) return -3; }
     return 0;
 }
 #endif

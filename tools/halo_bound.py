@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Host-only (no GPU): how often must the dual SpMM fetch a row of X from HBM, as a function of how many CONSECUTIVE plan
+blocks share one fetch?  A block stages its ~128 distinct source rows per slab; a row that several blocks need is fetched
+once only if those blocks read it while it still sits in the XCD's 4 MB L2, i.e. if they run CONCURRENTLY on that XCD (one
+slab step of its 32 workgroups streams ~3 MB through the L2).  The 32 workgroups of an XCD work on 32 consecutive blocks of
+the Hilbert order, so the bound that perfect lock-step could reach is the k = 32 row below; k = 1 is no sharing at all.
+
+    python tools/halo_bound.py [edges] > profiles/r04_spmm_halo_bound.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scone_gcn_amd import synthetic_data_gen as g
+from scone_gcn_amd.complex import SimplicialComplex
+
+edges = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+cx = g.random_SC_graph(g.calibrate_n_points(edges))
+sc = SimplicialComplex(cx)
+L_lo, L_up = sc.scone_shifts()
+csr = L_lo.device_csr().tocsr()                      # rows and columns in the layout's order, the plan's block cuts below
+bs = np.asarray(sc.layout.block_starts[1]).astype(bool)
+starts = np.nonzero(bs)[0]
+ends = np.append(starts[1:], len(bs))
+indptr, indices = csr.indptr, csr.indices
+E, K, S = csr.shape[0], 128, 32
+x_bytes = 4.0 * E * K * S
+out_bytes = 2 * x_bytes
+csr_bytes = 4.0 * (csr.nnz * 3 + E + 1)
+rows = {}
+for k in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    src = n = 0
+    for i in range(0, len(starts), k):
+        r0, r1 = starts[i], ends[min(i + k, len(starts)) - 1]
+        src += len(np.unique(np.concatenate([indices[indptr[r0]:indptr[r1]], np.arange(r0, r1)])))
+        n += r1 - r0
+    f = src / n
+    traffic = x_bytes * f + out_bytes + csr_bytes
+    rows[str(k)] = {"unique_sources_per_row": f, "hbm_bytes_per_launch": traffic,
+                    "ms_at_6.06_TBps": traffic / 6.06e12 * 1e3,
+                    "frac_of_8TBps_on_algorithmic_bytes": (x_bytes + out_bytes + csr_bytes) / (traffic / 6.06e12) / 8e12}
+print(json.dumps({
+    "what": "dual SpMM [S_lo X, S_up X], X [32 slabs, |E|=%d, K=128] fp32: HBM bytes per launch if every group of k consecutive "
+            "plan blocks fetched its distinct source rows exactly once (perfect sharing inside the group, none across groups), "
+            "and the launch time / roofline fraction that traffic allows at the 6.06 TB/s the kernel's LDS-DMA + stores floor moves "
+            "its bytes at (profiles/r03_spmm_ceiling.json)" % E,
+    "blocks": int(len(starts)), "rows_per_block": float(E / len(starts)), "algorithmic_bytes": x_bytes + out_bytes + csr_bytes,
+    "groups_of_k_consecutive_blocks": rows,
+    "reading": "k = 32 is what the 32 workgroups of an XCD can share when they run 32 neighbouring blocks in perfect lock-step "
+               "(one slab step of an XCD streams ~3 MB through its 4 MB L2, so nothing survives from one round to the next); the "
+               "measured 53.6 GB per launch (X fetched 1.25x) is 3 % above that bound, and the bound itself allows 0.69 of 8 TB/s."
+}, indent=1))
