@@ -41,10 +41,11 @@ def _check(loss, grads, ref_loss, ref_g, what):
     assert err <= REL_TO_MAX_GRAD * gmax
 
 
-@pytest.mark.parametrize("model,hidden", [("scone", 32), ("scone", 16), ("ebli", 32)])
+@pytest.mark.parametrize("model,hidden", [("scone", 32), ("scone", 16), ("ebli", 32), ("ebli", 16)])
 def test_loss_and_weight_gradients_match_the_csr_oracle_at_one_million_edges(big_complex, model, hidden):
     """scone (the fused C=32 / paired C=16 kernels + first-layer fast path) and ebli (ops.PowerPlan: L1^2 has rows too wide for
-    a block there, so S (S H) is composed) on 6 trajectories = 2 slabs, the second half padding."""
+    a block there, so S (S H) is composed: the fused power kernels at hidden 32, two ring SpMMs + the dense-term kernels per
+    layer at hidden 16) on 6 trajectories = 2 slabs, the second half padding."""
     from scone_gcn_amd import ops, scone_trajectory_model as stm, synthetic_data_gen as g, trajectory_experiments as te
     cx, sc = big_complex
     N = 6

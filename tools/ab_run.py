@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--libs", required=True, help="name=path,... (paths relative to the repo root)")
 ap.add_argument("--edges", type=int, default=1_000_000)
 ap.add_argument("--slabs", type=int, default=32)
+ap.add_argument("--hidden", type=int, default=32)
 ap.add_argument("--which", default="fwd,bwd,bwdf")
 ap.add_argument("--data", default="dense,sparse")
 ap.add_argument("--rounds", type=int, default=3)
@@ -43,7 +44,7 @@ for spec in a.libs.split(","):
     builds[name] = (lib, ops.SconePlan(shifts[0], shifts[1], readout, "tanh", dev))
     print("build %s: %s, plan blocks %s" % (name, path, builds[name][1].conv.plan_info()), flush=True)
 
-E, C, S = cx.n_edges, 32, a.slabs
+E, C, S = cx.n_edges, a.hidden, a.slabs
 torch.manual_seed(0)
 W = [torch.randn(C, C, device=dev) * 0.1 for _ in range(3)]
 W1 = [torch.randn(1, C, device=dev) * 0.1 for _ in range(3)]
