@@ -34,6 +34,9 @@ cx = g.random_SC_graph(g.calibrate_n_points(a.edges))
 sc = SimplicialComplex(cx)
 shifts, readout, _ = te.setup_from_complex(sc, "scone")
 dev = ops.default_device()
+bunch = any(k.startswith("t") for k in a.which.split(","))          # tfwd / tbwd: the fused Bunch layer (the model's third-layer launches)
+if bunch:
+    bshifts, bnbr, _ = te.setup_from_complex(sc, "bunch")
 builds = {}
 for spec in a.libs.split(","):
     name, path = spec.split("=")
@@ -41,8 +44,12 @@ for spec in a.libs.split(","):
     _lib._lib = None
     _lib.LIB_PATH = path
     lib = _lib.load()
-    builds[name] = (lib, ops.SconePlan(shifts[0], shifts[1], readout, "tanh", dev))
-    print("build %s: %s, plan blocks %s" % (name, path, builds[name][1].conv.plan_info()), flush=True)
+    if bunch:
+        builds[name] = (lib, ops.BunchPlan(bshifts, bnbr, dev))
+        print("build %s: %s (bunch)" % (name, path), flush=True)
+    else:
+        builds[name] = (lib, ops.SconePlan(shifts[0], shifts[1], readout, "tanh", dev))
+        print("build %s: %s, plan blocks %s" % (name, path, builds[name][1].conv.plan_info()), flush=True)
 
 E, C, S = cx.n_edges, a.hidden, a.slabs
 torch.manual_seed(0)
@@ -52,6 +59,16 @@ which = a.which.split(",")
 
 
 def call(plan, k, x, aux, yrec):
+    if k in ("tfwd", "tbwd"):
+        want = [True, True, False]
+        if k == "tfwd":
+            Wn = [[BW[l][j] if l != 2 else None for j in range(3)] for l in range(3)]
+            return [o for o in plan._terms_fwd_for(want).forward(bxs, Wn, "relu", want) if o is not None]
+        dzs = [bxs[0], bxs[1], None]
+        Wn = [[BWb[a_][b_] if b_ != 2 else None for b_ in range(3)] for a_ in range(3)]
+        dWn = [[torch.zeros(32, 32, device=dev) if (b_ != 2 and BWb[a_][b_] is not None) else None for b_ in range(3)] for a_ in range(3)]
+        out = ops._terms_backward(plan._terms_bwd_for([True, True, False]), dzs, Wn, bauxs, "relu", [True] * 3, dWn)
+        return [o for o in out if o is not None] + [d for row in dWn for d in row if d is not None]
     if k == "spmm":
         return plan.conv.spmm_dual(x.view(S, E, 4 * C))
     if k == "fwd":
@@ -72,6 +89,17 @@ def checksum(o):
     return " ".join(checksum(t) for t in o)
 
 
+if bunch:
+    sizes = next(iter(builds.values()))[1].sizes
+    BS = 16
+    bxs = [torch.randn((BS, n_, 4, 32), device=dev) for n_ in sizes]
+    bauxs = [torch.relu(torch.randn((BS, n_, 4, 32), device=dev)) for n_ in sizes]
+    BW = [[None] * 3 for _ in range(3)]
+    BWb = [[None] * 3 for _ in range(3)]
+    for k_ in range(7):
+        w_ = torch.randn(32, 32, device=dev) * 0.1
+        BW[ops.BUNCH_DST[k_]][ops.BUNCH_SRC[k_]] = w_
+        BWb[ops.BUNCH_SRC[k_]][ops.BUNCH_DST[k_]] = w_
 for data in a.data.split(","):
     x = torch.randn(S, E, 4, C, device=dev)
     if data == "sparse":      # like the benchmark's activations: ~5 % of the 64-row groups of a slab carry values, the rest exact zeros
