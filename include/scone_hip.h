@@ -139,6 +139,8 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
  *   logits[n,d] = sum_{e incident to v} sign(v,e) * (H[e,n,:] . w_last),  v = nbr[last[n]][d];  v = -1 -> 0
  *   logp = logits - logsumexp_d(logits)    over ALL D entries, padding included.
  * inc_* is B1 (optionally flipped, TE:291) as node-major CSR on device.
+ * max_deg (the neighbourhood width D = the largest node degree, TE:279) up to 1024: one slot per lane up to 64, LDS-resident slot
+ * arrays beyond (hub nodes); SCN_ERR_UNSUPPORTED above 1024.  The same holds for the node readout of the Bunch model below.
  * --------------------------------------------------------------------------------------------------- */
 int scn_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
                         const float* H, const float* w_last,

@@ -337,6 +337,159 @@ __global__ __launch_bounds__(64) void node_readout_bwd_kernel(int ns, int n_node
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same four kernels for neighbourhoods wider than one wave's lanes (RO_MAXD < max_deg <= RO_WIDE): hub nodes.  One wave per
+// trajectory as before; the per-slot values (logits, d_logits, neighbour ids) live in LDS arrays of RO_WIDE entries and the lanes
+// stride over the slots.  Plain loops: a complex with such a node is rare and its readout is still a sliver of the step.
+// ------------------------------------------------------------------------------------------------
+constexpr int RO_WIDE = 1024;
+
+__device__ __forceinline__ float lds_logsumexp(const float* vals, int n, int lane) {
+    float m = -INFINITY;
+    for (int d = lane; d < n; d += 64) m = fmaxf(m, vals[d]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int d = lane; d < n; d += 64) se += expf(vals[d] - m);
+    se = wave_sum(se);
+    return m + logf(se);
+}
+
+__global__ __launch_bounds__(64) void readout_fwd_wide_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+                                                              const float* __restrict__ w, const int32_t* __restrict__ nbr,
+                                                              int max_deg, const int32_t* __restrict__ last_nodes,
+                                                              const int32_t* __restrict__ inc_ptr,
+                                                              const int32_t* __restrict__ inc_edge,
+                                                              const float* __restrict__ inc_sign, float* __restrict__ bh,
+                                                              float* __restrict__ logits, float* __restrict__ logp) {
+    __shared__ float lgs[RO_WIDE];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    for (int d = 0; d < max_deg; ++d) {
+        const int v = nbr[(size_t)vlast * max_deg + d];
+        float lg = 0.f;
+        for (int c0 = 0; c0 < c; c0 += 64) {
+            const int cc = c0 + lane;
+            float acc = 0.f;
+            if (v >= 0 && cc < c)
+                for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j)
+                    acc = fmaf(inc_sign[j], H[(((size_t)s * n_edges + inc_edge[j]) * ns + i) * c + cc], acc);
+            if (cc < c) {
+                bh[((size_t)n * max_deg + d) * c + cc] = acc;
+                lg = fmaf(acc, w[cc], lg);
+            }
+        }
+        lg = wave_sum(lg);
+        if (lane == 0) lgs[d] = lg;
+    }
+    __syncthreads();
+    const float lse = lds_logsumexp(lgs, max_deg, lane);       // padding rows (logit 0) take part, as in the reference (TE:151-152)
+    for (int d = lane; d < max_deg; d += 64) {
+        logits[(size_t)n * max_deg + d] = lgs[d];
+        logp[(size_t)n * max_deg + d] = lgs[d] - lse;
+    }
+}
+
+__global__ __launch_bounds__(64) void readout_bwd_wide_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+                                                              const float* __restrict__ w, const int32_t* __restrict__ nbr,
+                                                              int max_deg, const int32_t* __restrict__ last_nodes,
+                                                              const int32_t* __restrict__ inc_ptr,
+                                                              const int32_t* __restrict__ inc_edge,
+                                                              const float* __restrict__ inc_sign,
+                                                              const int32_t* __restrict__ edge_nodes,
+                                                              const float* __restrict__ d_logp,
+                                                              const float* __restrict__ logp, int act,
+                                                              float* __restrict__ dz, float* __restrict__ dl_out, int clear) {
+    __shared__ float dl[RO_WIDE];
+    __shared__ int nb[RO_WIDE];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    float g = 0.f;
+    if (!clear)
+        for (int d = lane; d < max_deg; d += 64) g += d_logp[(size_t)n * max_deg + d];
+    const float gs = wave_sum(g);
+    for (int d = lane; d < max_deg; d += 64) {
+        if (!clear) {
+            const float v = d_logp[(size_t)n * max_deg + d] - expf(logp[(size_t)n * max_deg + d]) * gs;
+            dl[d] = v;
+            dl_out[(size_t)n * max_deg + d] = v;
+        } else {
+            dl[d] = 0.f;
+        }
+        nb[d] = nbr[(size_t)vlast * max_deg + d];
+    }
+    __syncthreads();
+    for (int d = 0; d < max_deg; ++d) {
+        const int v = nb[d];
+        if (v < 0) continue;
+        for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
+            const int e = inc_edge[j];
+            const int t = edge_nodes[2 * e], h = edge_nodes[2 * e + 1];
+            const int other = (t == v) ? h : t;
+            int dk = -1;                                       // slot of the edge's other endpoint, if it is a neighbour too (the last such slot)
+            for (int q = lane; q < max_deg; q += 64)
+                if (nb[q] == other) dk = q;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dk = max(dk, __shfl_xor(dk, o, 64));
+            if (dk >= 0 && other < v) continue;                // handled from the other endpoint's side
+            const size_t base = (((size_t)s * n_edges + e) * ns + i) * c;
+            if (clear) {
+                for (int cc = lane; cc < c; cc += 64) dz[base + cc] = 0.f;
+                continue;
+            }
+            const float coef = inc_sign[j] * (dl[d] - (dk >= 0 ? dl[dk] : 0.f));
+            for (int cc = lane; cc < c; cc += 64) dz[base + cc] = coef * w[cc] * act_grad_from_output(act, H[base + cc]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void node_readout_fwd_wide_kernel(int ns, int n_nodes, const float* __restrict__ X,
+                                                                   const int32_t* __restrict__ nbr, int max_deg,
+                                                                   const int32_t* __restrict__ last_nodes,
+                                                                   float* __restrict__ logits, float* __restrict__ logp) {
+    __shared__ float lgs[RO_WIDE];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    for (int d = lane; d < max_deg; d += 64) {
+        int v = nbr[(size_t)vlast * max_deg + d];
+        if (v < 0) v += n_nodes;                      // index -1 wraps to the last node (TE:201)
+        lgs[d] = X[((size_t)s * n_nodes + v) * ns + i];
+    }
+    __syncthreads();
+    const float lse = lds_logsumexp(lgs, max_deg, lane);
+    for (int d = lane; d < max_deg; d += 64) {
+        logits[(size_t)n * max_deg + d] = lgs[d];
+        logp[(size_t)n * max_deg + d] = lgs[d] - lse;
+    }
+}
+
+__global__ __launch_bounds__(64) void node_readout_bwd_wide_kernel(int ns, int n_nodes, const float* __restrict__ X,
+                                                                   const int32_t* __restrict__ nbr, int max_deg,
+                                                                   const int32_t* __restrict__ last_nodes,
+                                                                   const float* __restrict__ d_logp,
+                                                                   const float* __restrict__ logp, int act,
+                                                                   float* __restrict__ dz) {
+    __shared__ float dl[RO_WIDE];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int s = n / ns, i = n - s * ns;
+    const int vlast = last_nodes[n];
+    float g = 0.f;
+    for (int d = lane; d < max_deg; d += 64) g += d_logp[(size_t)n * max_deg + d];
+    const float gs = wave_sum(g);
+    for (int d = lane; d < max_deg; d += 64) dl[d] = d_logp[(size_t)n * max_deg + d] - expf(logp[(size_t)n * max_deg + d]) * gs;
+    __syncthreads();
+    if (lane == 0) {                                   // serial: several padded entries may hit the same node
+        for (int d = 0; d < max_deg; ++d) {
+            int v = nbr[(size_t)vlast * max_deg + d];
+            if (v < 0) v += n_nodes;
+            const size_t o = ((size_t)s * n_nodes + v) * ns + i;
+            dz[o] += dl[d] * act_grad_from_output(act, X[o]);
+        }
+    }
+}
+
 __global__ void scatter_flows_kernel(int ns, int n_edges, int64_t n_entries, const int32_t* __restrict__ sample_of,
                                      const int32_t* __restrict__ edge_idx, const float* __restrict__ val,
                                      float* __restrict__ x) {
@@ -397,9 +550,13 @@ int scn_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c,
     if (!H || !w_last || !nbr || !last_nodes || !inc_ptr || !inc_edge || !inc_sign || !bh || !logits || !logp)
         return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
-    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, H,
-                       w_last, nbr, max_deg, last_nodes, inc_ptr, inc_edge, inc_sign, bh, logits, logp);
+    if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
+    if (max_deg > RO_MAXD)
+        hipLaunchKernelGGL(readout_fwd_wide_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, H,
+                           w_last, nbr, max_deg, last_nodes, inc_ptr, inc_edge, inc_sign, bh, logits, logp);
+    else
+        hipLaunchKernelGGL(readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, H,
+                           w_last, nbr, max_deg, last_nodes, inc_ptr, inc_edge, inc_sign, bh, logits, logp);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
@@ -414,13 +571,17 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
         !d_logp || !logp || !d_logits || !dz || !d_w_last)
         return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
-    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int N = n_slabs * ns;
     if (!dz_is_zero) SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
     float* dl = d_logits;
-    hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
-                       last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
+    if (max_deg > RO_MAXD)
+        hipLaunchKernelGGL(readout_bwd_wide_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
+                           last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
+    else
+        hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
+                           last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(readout_dw_kernel, dim3(1), dim3(1024), 0, st, N * max_deg, c, dl, bh, d_w_last);
     SCN_LAUNCH_CHECK();
@@ -432,10 +593,15 @@ int scn_readout_clear_dz(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
                          const int32_t* edge_nodes, float* dz, void* stream) {
     if (!nbr || !last_nodes || !inc_ptr || !inc_edge || !edge_nodes || !dz) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_edges <= 0 || c <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
-    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(readout_bwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, nullptr,
-                       nullptr, nbr, max_deg, last_nodes, inc_ptr, inc_edge, nullptr, edge_nodes, nullptr, nullptr, 0, dz,
-                       nullptr, 1);
+    if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
+    if (max_deg > RO_MAXD)
+        hipLaunchKernelGGL(readout_bwd_wide_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, nullptr,
+                           nullptr, nbr, max_deg, last_nodes, inc_ptr, inc_edge, nullptr, edge_nodes, nullptr, nullptr, 0, dz,
+                           nullptr, 1);
+    else
+        hipLaunchKernelGGL(readout_bwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_edges, c, nullptr,
+                           nullptr, nbr, max_deg, last_nodes, inc_ptr, inc_edge, nullptr, edge_nodes, nullptr, nullptr, 0, dz,
+                           nullptr, 1);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
@@ -445,9 +611,13 @@ int scn_node_readout_forward(int32_t n_slabs, int32_t ns, int32_t n_nodes, const
                              float* logp, void* stream) {
     if (!nodes_out || !nbr || !last_nodes || !logits || !logp) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
-    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(node_readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_nodes,
-                       nodes_out, nbr, max_deg, last_nodes, logits, logp);
+    if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
+    if (max_deg > RO_MAXD)
+        hipLaunchKernelGGL(node_readout_fwd_wide_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_nodes,
+                           nodes_out, nbr, max_deg, last_nodes, logits, logp);
+    else
+        hipLaunchKernelGGL(node_readout_fwd_kernel, dim3(n_slabs * ns), dim3(64), 0, (hipStream_t)stream, ns, n_nodes,
+                           nodes_out, nbr, max_deg, last_nodes, logits, logp);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }
@@ -457,12 +627,16 @@ int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes, cons
                               const float* logp, int32_t act, float* dz, void* stream) {
     if (!nodes_out || !nbr || !last_nodes || !d_logp || !logp || !dz) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || max_deg <= 0) return SCN_ERR_BAD_SHAPE;
-    if (max_deg > RO_MAXD) return SCN_ERR_UNSUPPORTED;
+    if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int N = n_slabs * ns;
     SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_nodes, st));
-    hipLaunchKernelGGL(node_readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_nodes, nodes_out, nbr, max_deg,
-                       last_nodes, d_logp, logp, act, dz);
+    if (max_deg > RO_MAXD)
+        hipLaunchKernelGGL(node_readout_bwd_wide_kernel, dim3(N), dim3(64), 0, st, ns, n_nodes, nodes_out, nbr, max_deg,
+                           last_nodes, d_logp, logp, act, dz);
+    else
+        hipLaunchKernelGGL(node_readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_nodes, nodes_out, nbr, max_deg,
+                           last_nodes, d_logp, logp, act, dz);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -1143,3 +1143,66 @@ def test_fused_bunch_layer_operator_matches_scipy(drop):
         for k in gk:
             refw = np.einsum("srnc,srnd->cd", auxs[a].astype(np.float64), gk[k]) + 0.5
             assert _maxdiff(dWb[a][DST[k]].cpu().numpy(), refw) <= 2e-5 * max(1.0, np.abs(refw).max())
+
+
+@pytest.mark.parametrize("model", ["scone", "bunch"])
+def test_readout_on_a_hub_node_wider_than_one_wave(model):
+    """A node of degree 90: neighbourhoods (TE:279) are 90 wide, more than the 64 lanes the readout kernels give one slot each
+    (they returned SCN_ERR_UNSUPPORTED until round 4).  Trajectories that END AT THE HUB (90 live slots) and next to it (the hub
+    among the neighbours, 80-odd padding rows inside the logsumexp, TE:151-152): loss and every weight gradient against the oracle."""
+    _need_gpu()
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    base = g.random_SC_graph(500)
+    hub = base.n_nodes
+    near = np.argsort(np.linalg.norm(base.coords - [0.5, 0.5], axis=1))[:90]
+    inset = np.zeros(hub + 1, bool)
+    inset[near] = True
+    spokes = np.stack([near, np.full(len(near), hub)], axis=1)
+    rim = base.edges[inset[base.edges[:, 0]] & inset[base.edges[:, 1]]]
+    cones = np.concatenate([rim, np.full((len(rim), 1), hub)], axis=1)
+    cx = g.Complex(n_nodes=hub + 1, edges=np.unique(np.concatenate([base.edges, spokes]), axis=0),
+                   faces=np.unique(np.concatenate([base.faces, cones]), axis=0),
+                   coords=np.concatenate([base.coords, [[0.5, 0.5]]]))
+    sc = SimplicialComplex(cx)
+    D = sc.max_degree
+    assert D == 90
+    paths = g.generate_random_walks(base, m=10, seed=5)
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=2)
+    n = len(paths)
+    last = np.asarray(last[:n]).copy()
+    choice = np.asarray(choice[:n]).copy()
+    last[:3] = hub                                                   # end at the hub: all 90 slots live
+    choice[:3] = [0, 57, 89]
+    last[3:5] = near[:2]                                             # end next to it
+    choice[3:5] = 0
+    X = flows.todense()[:n].astype(np.float64)
+    y = so.onehot_targets(choice, D)
+    B1, B2 = g.incidence_matrices(cx)
+    if model == "scone":
+        w = _rand_weights(so.weight_shapes(1, [(3, 16)] * 3, 1), 0.15, 3)
+        L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+        import scipy.sparse as sp
+        B1x = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()
+        Bc = lambda v: B1x[sc.nbrhoods[v]].toarray()
+        ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, Bc, last, X, y, np.ones(n, int), 0.0)
+        shifts, readout, _ = te.setup_from_complex(sc, "scone")
+        args = (*shifts, readout, last, X)
+        fn = te.scone_func
+    else:
+        w = _rand_weights(so.weight_shapes(1, [(7, 8)] * 2, 1, "bunch"), 0.3, 5)
+        S = [m.tocsr() for m in compute_shift_matrices(B1, B2)]
+        ref_loss, ref_g = so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, np.ones(n, int), 0.0)
+        shifts, nbrhoods, _ = te.setup_from_complex(sc, "bunch")
+        args = (*shifts, nbrhoods, last, X)
+        fn = te.bunch_func
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = fn(wt, *args)
+    assert tuple(out.shape) == (n, D, 1)
+    loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / n
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
