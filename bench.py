@@ -588,6 +588,9 @@ def main():
                                               sync, layers=[(3, 32), (3, 16)])
         configs["uniform 2x32"] = side_config("-hidden_layers [(3,32),(3,32)], |E|~1M, batch 128 (reference point for the mixed stack)",
                                               "scone", cx, sc, 32, 128, 3, sync, layers=[(3, 32), (3, 32)])
+        # a hidden width above 32 (-hidden_layers takes any, TE:103-110): 32-channel blocks on the same fused kernels (ops.SconePlan._wide_stack)
+        configs["hidden 64"] = side_config("-hidden_layers [(3,64)]*3, |E|~1M, batch 128 (32-channel blocks on the hidden-32 kernels)", "scone",
+                                           cx, sc, 64, 128, 2, sync)
         del plan, inputs
         # configs[1]: |E| ~ 50k, hidden 16, batch 1024
         cx2 = g.random_SC_graph(g.calibrate_n_points(50_000))

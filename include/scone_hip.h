@@ -191,6 +191,12 @@ int scn_node_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_nodes,
  *                     dW2[a][c] += relu(w1[a]) u_pos[c] + min(w1[a], 0) u_neg[c],
  *                     dw1[a]    += [w1[a] > 0] (u_pos @ W2^T)[a] + [w1[a] < 0] (u_neg @ W2^T)[a]      (relu'(0) = 0, as everywhere). */
 int scn_split_sign(int64_t n, const float* g, float* g_pos, float* g_neg, void* stream);
+
+/* out[i] = act(terms[0][i] + ... + terms[n_terms-1][i]), n floats (a multiple of 4, 16-byte aligned tensors), 1 <= n_terms <= 4, summed
+ * in term order; out may be terms[0].  Hidden widths above 32 (-hidden_layers, TE:103-110): a layer of scone_func / ebli_func
+ * (TE:143-149) runs as its (input block, output block) pairs of 32 channels on the fused kernels; this adds the partial
+ * pre-activations of an output block (forward) and the partial input gradients of an input block (backward, act = none). */
+int scn_sum_act(int64_t n, int32_t n_terms, const float* const* terms, int32_t act, float* out, void* stream);
 int scn_fold1_forward(const float* w1, const float* W2, int32_t c1, int32_t c2, float* a_pos, float* a_neg, void* stream);
 int scn_fold1_backward(const float* w1, const float* W2, const float* u_pos, const float* u_neg, int32_t c1, int32_t c2,
                        float* dW2, float* dw1, void* stream);

@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256) void split_sign_kernel(int64_t n, const float*
     }
 }
 
+// out = act(t0 + t1 [+ t2 + t3]) elementwise, 16 bytes per thread and trip (hidden widths above 32: the partial pre-activations /
+// partial input gradients of a layer's 32-channel blocks, summed in term order; out may be t0)
+struct SumTerms { const float* t[4]; int n; };
+template <int ACT>
+__global__ __launch_bounds__(256) void sum_act_kernel(int64_t n4, SumTerms T, float* out) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = ((const f32x4*)T.t[0])[i];
+        for (int k = 1; k < T.n; ++k) v += ((const f32x4*)T.t[k])[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply_fast(ACT, v[j]);
+        ((f32x4*)out)[i] = v;
+    }
+}
+
 // Ap[c] = sum_a relu(w1[a]) W2[a][c],  Am[c] = sum_a min(w1[a], 0) W2[a][c]        (one workgroup, thread = output channel)
 __global__ void fold1_forward_kernel(const float* __restrict__ w1, const float* __restrict__ W2, int c1, int c2,
                                      float* __restrict__ Ap, float* __restrict__ Am) {
@@ -628,6 +643,30 @@ int scn_dense_terms_backward(int64_t n_points, int32_t n_terms, const float* con
     SCN_LAUNCH_CHECK();
     r.partial = a.partial; r.n_partials = nb; r.total = r.off[n_terms]; r.n_terms = n_terms;
     hipLaunchKernelGGL(dense_dw_reduce, dim3((r.total + 255) / 256), dim3(256), 0, st, r);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_sum_act(int64_t n, int32_t n_terms, const float* const* terms, int32_t act, float* out, void* stream) {
+    if (!terms || !out) return SCN_ERR_BAD_ARG;
+    if (n <= 0 || (n & 3) || n_terms < 1 || n_terms > 4) return SCN_ERR_BAD_SHAPE;
+    SumTerms T{};
+    T.n = n_terms;
+    for (int k = 0; k < n_terms; ++k) {
+        if (!terms[k] || ((uintptr_t)terms[k] & 15)) return SCN_ERR_BAD_ARG;
+        T.t[k] = terms[k];
+    }
+    if ((uintptr_t)out & 15) return SCN_ERR_BAD_ARG;
+    const int64_t n4 = n / 4;
+    const dim3 grid((int)std::min<int64_t>(8192, (n4 + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (act) {
+        case SCN_ACT_TANH: hipLaunchKernelGGL(sum_act_kernel<SCN_ACT_TANH>, grid, dim3(256), 0, st, n4, T, out); break;
+        case SCN_ACT_RELU: hipLaunchKernelGGL(sum_act_kernel<SCN_ACT_RELU>, grid, dim3(256), 0, st, n4, T, out); break;
+        case SCN_ACT_LEAKY_RELU: hipLaunchKernelGGL(sum_act_kernel<SCN_ACT_LEAKY_RELU>, grid, dim3(256), 0, st, n4, T, out); break;
+        case SCN_ACT_NONE: hipLaunchKernelGGL(sum_act_kernel<SCN_ACT_NONE>, grid, dim3(256), 0, st, n4, T, out); break;
+        default: return SCN_ERR_BAD_ARG;
+    }
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

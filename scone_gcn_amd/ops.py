@@ -558,13 +558,27 @@ def _last_nodes_dev(last_nodes, n_pad, device):
 # channels are exactly zero in every activation and every gradient, the real channels see the same sums (the extra terms
 # are exact zeros), and the padded rows / columns of the weight gradients are dropped again on the way out.
 
-def promoted_width(widths):
-    """Width every hidden layer is padded to, or None when the stack runs as it is (uniform 16 or 32, or wider than 32)."""
+WIDE_MAX = 128        # widest hidden layer served by the 32-channel-block decomposition (SconePlan._wide_stack)
+
+
+def promoted_width(widths, wide=False):
+    """Width every hidden layer is padded to, or None when the stack runs as it is (uniform 16 or 32; wider than 32 unless
+    `wide`: then the next multiple of 32 up to WIDE_MAX -- such a stack runs in 32-channel blocks)."""
     ws = {int(c) for c in widths}
     if len(ws) == 1 and ws <= {16, 32}:
         return None
     m = max(ws)
-    return 16 if m <= 16 else (32 if m <= 32 else None)
+    if m > 32:
+        return -(-m // 32) * 32 if (wide and m <= WIDE_MAX) else None
+    return 16 if m <= 16 else 32
+
+
+def sum_act(terms, act, out=None):
+    """out = act(terms[0] + terms[1] + ...) elementwise (scn_sum_act; out defaults to terms[0], in place)."""
+    out = terms[0] if out is None else out
+    check(_lib.load().scn_sum_act(out.numel(), len(terms), ptr_array([_dev(t).value for t in terms]), ACT[act], _dev(out), _stream()),
+          "scn_sum_act")
+    return out
 
 
 def promote_weights(weights, n_first, n_last, P):
@@ -768,7 +782,7 @@ class SconePlan:
 
     def release(self, saved):
         """Forward-only use of the zero-skipping mode (prediction): hand the forward's pooled buffers back, all-zero again."""
-        hs, bh, y0, activity, _ = saved
+        hs, bh, y0, activity = saved[:4]
         if activity:
             for l in range(1, len(hs)):
                 self._give_back(hs[l], activity["fwd"][l - 1])
@@ -800,15 +814,78 @@ class SconePlan:
         """Promoted hidden width of this weight list on this plan (None: runs as it is)."""
         if len(weights) < 4 or (len(weights) - 1) % 3 or not self._blocked():
             return None
-        return promoted_width([w.shape[1] for w in weights[:-1]])
+        # widths above 32: in 32-channel blocks (_wide_stack) on the fused plan proper (the composed Ebli plan keeps its dense-term path)
+        return promoted_width([w.shape[1] for w in weights[:-1]], wide=type(self) is SconePlan and weights[0].shape[0] == 1)
 
     def forward(self, x, last_dev, weights, activity=None):
         P = self.promotion(weights)
         wp = promote_weights(weights, 3, 1, P) if P else None
         w = wp if P else weights
+        if P and P > 32:
+            hs, y0 = self._wide_stack(x, w, P)
+            H = torch.cat(hs[-1], dim=3)                # the readout reads one (S, E, ns, P) tensor
+            logp, bh, _ = self.readout(H, w[-1], last_dev)
+            return logp, (hs, bh, y0, None, wp, H)
         hs, y0 = self.conv_stack(x, w, activity)
         logp, bh, _ = self.readout(hs[-1], w[-1], last_dev)
         return logp, (hs, bh, y0, activity, wp)
+
+    # -- hidden widths above 32 (TE:103-110 accepts any): every activation is P / 32 separate 32-channel tensors and a layer is
+    # its (input block i, output block j) pairs on the fused C = 32 kernels -- act(sum_i sum_s (S_s H_i) W_s[i, j]) (TE:143-149):
+    # the partial pre-activations of an output block are added and activated by scn_sum_act; in the backward the partial input
+    # gradients of an input block add up likewise (act' of the layer below is a common factor of the partial results).  The
+    # same products in the same association order per 32 x 32 weight block; ~4x the hidden-32 step at hidden 64 instead of the
+    # generic one-row-per-workgroup kernels (measured 236x, DESIGN.md section 3.3).
+    @staticmethod
+    def _wblock(W, i, j):
+        r = slice(None) if W.shape[0] == 1 else slice(32 * i, 32 * i + 32)
+        return W[r, 32 * j:32 * j + 32].contiguous()
+
+    def _wide_stack(self, x, w, P):
+        k, L = P // 32, (len(w) - 1) // 3
+        hs, y0 = [[x]], None
+        for l in range(L):
+            W, prev, outs = w[3 * l:3 * l + 3], hs[-1], []
+            for j in range(k):
+                if l == 0:
+                    first = self.conv.forward_first(x, [self._wblock(Ws, 0, j) for Ws in W], 32, self.act)
+                    assert first is not None, "wide hidden layers need the first-layer fast path (1-channel flows)"
+                    outs.append(first[0])
+                    y0 = first[1] if y0 is None else y0
+                else:
+                    parts = [self.conv.forward([prev[i]], [self._wblock(Ws, i, j) for Ws in W], 32,
+                                               self.act if len(prev) == 1 else "none") for i in range(len(prev))]
+                    outs.append(parts[0] if len(parts) == 1 else sum_act(parts, self.act))
+            hs.append(outs)
+        return hs, y0
+
+    def _wide_backward(self, saved, logp, d_logp, last_dev, w, grads):
+        hs, bh, y0, _, _, H = saved
+        P = H.shape[3]
+        k, L = P // 32, len(hs) - 1
+        dz_top, key = self._readout_grad(H, bh, logp, d_logp, last_dev, w, grads)
+        dzs = [dz_top[..., 32 * j:32 * j + 32].contiguous() for j in range(k)]
+        self._release_top(dz_top, key, last_dev)
+        for l in reversed(range(L)):
+            W, G = w[3 * l:3 * l + 3], grads[3 * l:3 * l + 3]
+            if l == 0:                                  # dW_s[0, j] = sum_p (S_s x)[p] dz_j[p]: one stream over dz per block
+                for j in range(k):
+                    gj = [torch.zeros((1, 32), device=self.device, dtype=torch.float32) for _ in range(3)]
+                    assert self.conv.dw_first(hs[0][0], y0, dzs[j], gj)
+                    for Gs, g in zip(G, gj):
+                        Gs[:, 32 * j:32 * j + 32] += g
+                break
+            new = []
+            for i in range(len(hs[l])):
+                parts = []
+                for j in range(k):
+                    gij = [torch.zeros((32, 32), device=self.device, dtype=torch.float32) for _ in range(3)]
+                    parts.append(self.conv_T.backward([dzs[j]], [self._wblock(Ws, i, j) for Ws in W], hs[l][i], self.act, True, gij))
+                    for Gs, g in zip(G, gij):
+                        Gs[32 * i:32 * i + 32, 32 * j:32 * j + 32] += g
+                new.append(parts[0] if len(parts) == 1 else sum_act(parts, "none"))
+            dzs = new
+        return grads
 
     def _readout_grad(self, H, bh, logp, d_logp, last_dev, weights, grads):
         """Gradient of the readout w.r.t. the last layer's pre-activation, into a pooled all-zero buffer (it is zero except
@@ -840,12 +917,13 @@ class SconePlan:
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         """grads: list of tensors (same shapes as weights) accumulated into."""
         wp = saved[4]
+        run = self._wide_backward if len(saved) == 6 else self._backward
         if wp is not None:                              # promoted widths: gradients of the padded matrices, cut back afterwards
             gp = [torch.zeros_like(w) if w is not w0 else g for w, w0, g in zip(wp, weights, grads)]
-            self._backward(saved, logp, d_logp, last_dev, wp, gp)
+            run(saved, logp, d_logp, last_dev, wp, gp)
             demote_grads(grads, gp)
             return grads
-        return self._backward(saved, logp, d_logp, last_dev, weights, grads)
+        return run(saved, logp, d_logp, last_dev, weights, grads)
 
     def _backward(self, saved, logp, d_logp, last_dev, weights, grads):
         hs, bh, y0, activity, _ = saved

@@ -83,7 +83,9 @@ def test_forward_and_gradients_match_oracle(cfg1, sc1, model, hidden):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
 
 
-@pytest.mark.parametrize("model,layers", [("scone", [(3, 32), (3, 16)]), ("scone", [(3, 16), (3, 32)]),
+@pytest.mark.parametrize("model,layers", [("scone", [(3, 64)] * 3), ("scone", [(3, 48), (3, 64)]), ("scone", [(3, 64), (3, 32)]),
+                                          ("ebli", [(3, 96), (3, 40)]),         # widths above 32: 32-channel blocks (ops.SconePlan._wide_stack)
+                                          ("scone", [(3, 32), (3, 16)]), ("scone", [(3, 16), (3, 32)]),
                                           ("ebli", [(3, 32), (3, 16)]), ("ebli", [(3, 16), (3, 32)]),
                                           ("scone", [(3, 8), (3, 8)]), ("scone", [(3, 16), (3, 24), (3, 8)])])
 def test_reference_documented_layer_shapes_match_oracle(cfg1, sc1, model, layers):
@@ -108,9 +110,10 @@ def test_reference_documented_layer_shapes_match_oracle(cfg1, sc1, model, layers
         yt = torch.as_tensor(y, dtype=torch.float32, device="cuda")
         loss = -(out[m] * yt[m]).sum() / m.sum()
         loss.backward()
-    P = ops.promoted_width([c for _, c in layers])
+    P = min(32, ops.promoted_width([c for _, c in layers], wide=True))         # widths above 32 run in 32-channel blocks
     keys = list(kt.summary())
     assert any(k == "conv_fwd c%d->%d" % (P, P) for k in keys), keys           # the uniform-width MFMA kernels carried it
+    assert not any("c48" in k or "c64" in k or "c96" in k or "c40" in k for k in keys), keys   # never the generic one-row-per-workgroup path
     assert _maxdiff(out.detach().cpu().numpy(), ref_out) <= TOL
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
