@@ -440,6 +440,10 @@ def _pairable(widths, ns):
     return ns % 2 == 0 and all(int(c) == 16 for c in widths)
 
 
+DENSE_FWD_LDS = 64 * 1024      # scn_dense_terms_forward: bytes of LDS its weight matrices may take
+DENSE_BWD_WW = 1024            # scn_dense_terms_backward: c_aux * c_k it serves (one 32 x 32 weight-gradient tile per term)
+
+
 def dense_terms_forward(Gs, Ws, c_out, act):
     """out[p,:] = act(sum_k G_k[p,:] @ W_k) over slab tensors [S, rows, ns, c_k] (scn_dense_terms_forward)."""
     lib = _lib.load()
@@ -447,6 +451,26 @@ def dense_terms_forward(Gs, Ws, c_out, act):
     if _pairable([g.shape[3] for g in Gs] + [c_out], ns):
         out = dense_terms_forward([g.view(S, R, ns // 2, 32) for g in Gs], [torch.block_diag(w, w) for w in Ws], 32, act)
         return out.view(S, R, ns, 16)
+    cins = [g.shape[3] for g in Gs]
+    if max(cins + [c_out]) > 32 and c_out % 32 == 0 and all(c % 32 == 0 for c in cins):
+        # widths above 32 (multiples of 32: promotion pads to them) as 32 x 32 blocks on the MFMA kernel -- the partial
+        # pre-activations of an output block add up in scn_sum_act; the VALU kernel took 85 ms for one 64-wide launch at |E| = 1M
+        nb_in = max(cins) // 32
+        blocks = [[g if c == 32 else g[..., 32 * b:32 * b + 32].contiguous() for b in range(c // 32)] for g, c in zip(Gs, cins)]
+        outs = []
+        for j in range(c_out // 32):
+            parts = []
+            for b in range(nb_in):
+                sel = [k for k, c in enumerate(cins) if c > 32 * b]
+                parts.append(dense_terms_forward([blocks[k][b] for k in sel],
+                                                 [Ws[k][32 * b:32 * b + 32, 32 * j:32 * j + 32].contiguous() for k in sel], 32,
+                                                 act if nb_in == 1 else "none"))
+            outs.append(parts[0] if len(parts) == 1 else sum_act(parts, act))
+        return torch.cat(outs, dim=3)
+    if 4 * c_out * sum(cins) > DENSE_FWD_LDS and c_out > 32:
+        # the kernel keeps every W_k in LDS (64 KB): wider outputs run as column blocks of 32 (independent: no sums)
+        return torch.cat([dense_terms_forward(Gs, [w[:, c0:c0 + 32].contiguous() for w in Ws], min(32, c_out - c0), act)
+                          for c0 in range(0, c_out, 32)], dim=3)
     out = torch.empty((S, R, ns, c_out), device=Gs[0].device, dtype=torch.float32)
     with _timed("dense_fwd x%d ->%d" % (len(Gs), c_out), _nbytes(out, *Gs)):
         check(lib.scn_dense_terms_forward(S * R * ns, len(Gs), ptr_array([_dev(g).value for g in Gs]),
@@ -465,6 +489,8 @@ def dense_terms_backward(Gs, Ws, aux, act, need_dx, dWs):
         for d, w in zip(dWs, wide):                       # the two diagonal blocks of the virtual 32x32 gradient
             d.add_(w[:16, :16] + w[16:, 16:])
         return dx.view(S, R, ns, 16) if need_dx else None
+    if any(c_aux * g.shape[3] > DENSE_BWD_WW for g in Gs) and max(c_aux, max(g.shape[3] for g in Gs)) > 1:
+        return _dense_terms_backward_blocks(Gs, Ws, aux, act, need_dx, dWs)
     cs = i32_array([g.shape[3] for g in Gs])
     n_points = S * R * ns
     nbytes = lib.scn_dense_terms_backward_workspace(n_points, len(Gs), cs, c_aux)
@@ -547,6 +573,50 @@ def _last_nodes_dev(last_nodes, n_pad, device):
     a = last_nodes.detach().cpu().numpy() if torch.is_tensor(last_nodes) else np.asarray(last_nodes)
     ln[:len(a)] = a
     return torch.from_numpy(ln).to(device)
+
+
+def _dense_terms_backward_blocks(Gs, Ws, aux, act, need_dx, dWs):
+    """dense_terms_backward beyond the kernel's widths (c_aux * c_k > 1024): aux in channel blocks of <= 32 (independent: the
+    block's rows of every W_k and dW_k), and where a term is wider than 32 its channels in blocks of 32 as well -- the partial
+    input gradients of an aux block, each already times act'(aux), add up (scn_sum_act).  W_k: (c_aux, c_k)."""
+    c_aux = aux.shape[3]
+    cmax = max(g.shape[3] for g in Gs)
+    kb = -(-cmax // 32) if cmax > 32 else 1             # channel blocks of the widest term
+    dxs = []
+    for a0 in range(0, c_aux, 32):
+        a1 = min(c_aux, a0 + 32)
+        aux_a = aux[..., a0:a1].contiguous()
+        parts = []
+        for j in range(kb):
+            sel = [(k, 32 * j, min(g.shape[3], 32 * j + 32)) for k, g in enumerate(Gs) if g.shape[3] > 32 * j] if kb > 1 else \
+                  [(k, 0, g.shape[3]) for k, g in enumerate(Gs)]
+            if not sel:
+                continue
+            Gj = [Gs[k] if (c0 == 0 and c1 == Gs[k].shape[3]) else Gs[k][..., c0:c1].contiguous() for k, c0, c1 in sel]
+            Wj = [Ws[k][a0:a1, c0:c1].contiguous() for k, c0, c1 in sel]
+            dWj = [torch.zeros_like(w) for w in Wj]
+            parts.append(dense_terms_backward(Gj, Wj, aux_a, act, need_dx, dWj))
+            for (k, c0, c1), d in zip(sel, dWj):
+                dWs[k][a0:a1, c0:c1] += d
+        if need_dx:
+            dxs.append(parts[0] if len(parts) == 1 else sum_act(parts, "none"))
+    return torch.cat(dxs, dim=3) if need_dx else None
+
+
+def spmm_chunked(op, x):
+    """y = S x for a slab tensor x (S, R, ns, c) of ANY width: the LDS-blocked SpMM takes ns * c <= 128 columns per launch, wider
+    operands go through it in channel blocks (the shift acts on every channel alike)."""
+    S, R, ns, c = x.shape
+    step = max(1, 128 // ns)
+    if c <= step:
+        y, _ = op.spmm_dual(x.view(S, R, ns * c), dual=False)
+        return y.view(S, op.n_rows, ns, c)
+    outs = []
+    for c0 in range(0, c, step):
+        w = min(step, c - c0)
+        y, _ = op.spmm_dual(x[..., c0:c0 + w].contiguous().view(S, R, ns * w), dual=False)
+        outs.append(y.view(S, op.n_rows, ns, w))
+    return torch.cat(outs, dim=3)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -815,13 +885,15 @@ class SconePlan:
         if len(weights) < 4 or (len(weights) - 1) % 3 or not self._blocked():
             return None
         # widths above 32: in 32-channel blocks (_wide_stack) on the fused plan proper (the composed Ebli plan keeps its dense-term path)
-        return promoted_width([w.shape[1] for w in weights[:-1]], wide=type(self) is SconePlan and weights[0].shape[0] == 1)
+        # (widths above 32: the fused plan runs them in 32-channel blocks, _wide_stack; the composed Ebli plan pads them to a multiple
+        # of 32 as well, so that its dense-term kernels run as 32 x 32 MFMA blocks)
+        return promoted_width([w.shape[1] for w in weights[:-1]], wide=weights[0].shape[0] == 1)
 
     def forward(self, x, last_dev, weights, activity=None):
         P = self.promotion(weights)
         wp = promote_weights(weights, 3, 1, P) if P else None
         w = wp if P else weights
-        if P and P > 32:
+        if P and P > 32 and type(self) is SconePlan:
             hs, y0 = self._wide_stack(x, w, P)
             H = torch.cat(hs[-1], dim=3)                # the readout reads one (S, E, ns, P) tensor
             logp, bh, _ = self.readout(H, w[-1], last_dev)
@@ -979,9 +1051,7 @@ class PowerPlan(SconePlan):
 
     @staticmethod
     def _shift(op, x):
-        S, R, ns, c = x.shape
-        y, _ = op.spmm_dual(x.view(S, R, ns * c), dual=False)
-        return y.view(S, R, ns, c)
+        return spmm_chunked(op, x)
 
     def activity(self, *a, **k):
         return None
@@ -1159,12 +1229,10 @@ class BunchPlan:
 
     @staticmethod
     def _blocked_ok(ns, c):
-        return (ns * c) % 4 == 0 and ns * c <= 128
+        return (ns * c) % 4 == 0                        # (any width: operands wider than 128 columns go in channel blocks)
 
     def _spmm(self, op, x):
-        S, R, ns, c = x.shape
-        y, _ = op.spmm_dual(x.view(S, R, ns * c), dual=False)
-        return y.view(S, op.n_rows, ns, c)
+        return spmm_chunked(op, x)
 
     def conv_stack(self, x, weights):
         n_layers = len(weights) / 7
@@ -1316,7 +1384,7 @@ class BunchPlan:
     def promotion(self, weights):
         if len(weights) < 14 or len(weights) % 7:
             return None
-        return promoted_width([w.shape[1] for w in weights[:-7]])
+        return promoted_width([w.shape[1] for w in weights[:-7]], wide=True)   # above 32: multiples of 32 (32 x 32 MFMA blocks of the dense terms)
 
     def forward(self, x, last_dev, weights):
         lib = _lib.load()
