@@ -81,3 +81,112 @@ def test_random_case_matches_oracle(seed, model):
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss)), what
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "%s: weight %d" % (what, k)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_zero_skipping_step_equals_dense(seed):
+    """Exact zero-skipping (work lists) == the dense step on random complexes, widths, batch sizes and modes: loss and every
+    weight gradient (to the summation order of the weight-gradient partials), twice in a row (the pooled buffers must come back
+    all-zero), hidden 16 (slab pairs) and 32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    rs = np.random.RandomState(77 + seed)
+    cx = g.random_SC_graph(int(rs.randint(2500, 9000)), holes=bool(rs.randint(2)))
+    sc = SimplicialComplex(cx)
+    N = int(rs.choice([3, 6, 10, 17, 30]))
+    paths = g.generate_random_walks(cx, m=N, seed=int(rs.randint(1 << 20)), waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=int(rs.randint(1 << 20)))
+    N = len(paths)
+    y = so.onehot_targets(np.asarray(choice[:N]), sc.max_degree)
+    hidden = int(rs.choice([16, 32]))
+    mode = str(rs.choice(["zeros", "field"]))
+    model = str(rs.choice(["scone", "ebli"])) if int(np.diff(sc.ebli_shifts()[1].csr.indptr).max()) < 128 else "scone"
+    shifts, readout, _ = te.setup_from_complex(sc, model)
+    inputs = [readout, last, flows]
+    res = {}
+    for m in ("dense", mode):
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-3, N, 5e-5, verbose=False, skip_mode=m)
+        net.setup(te.MODEL_FUNCS[model], [(3, hidden)] * int(2 + seed % 2), shifts, inputs, y, None, np.ones(N, int), model_type=model)
+        for w in net.weights:
+            w.mul_(20.0 if model == "scone" else 3.0)
+        staged = net.stage(inputs, y, np.arange(N))
+        loss = float(net.grad_step_staged(inputs, staged, N, apply=False))
+        g1 = [t.detach().cpu().numpy().astype(np.float64) for t in net._grads]
+        assert float(net.grad_step_staged(inputs, staged, N, apply=False)) == loss
+        res[m] = (loss, g1, staged[0][3])
+    what = "%s hidden %d mode %s E %d batch %d" % (model, hidden, mode, cx.n_edges, N)
+    if res[mode][2] is None:
+        pytest.skip("work lists not served for " + what)
+    assert abs(res[mode][0] - res["dense"][0]) <= 1e-6 * max(1.0, abs(res["dense"][0])), what
+    gmax = max(float(np.abs(a).max()) for a in res["dense"][1])
+    for a, b in zip(res[mode][1], res["dense"][1]):
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(gmax, 1e-30), what
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_trainer_steps_match_oracle_adam(seed):
+    """Scone_GCN.grad_step (STM:306-326: masked batch, gradient of the loss with its ridge term, Adam with the (i + 1) bias
+    correction) for three consecutive steps on random complexes / models / widths / batch masks, through whatever path the
+    trainer picks (HIP-graph replay on fixed staging buffers for these small complexes, eager otherwise), against the oracle's
+    gradient + oracle Adam: weights after every step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    rs = np.random.RandomState(4242 + seed)
+    model = ["scone", "ebli", "bunch"][seed % 3]
+    cx = g.random_SC_graph(int(rs.randint(90, 400)), holes=bool(rs.randint(2)))
+    sc = SimplicialComplex(cx)
+    N = int(rs.choice([9, 14, 23, 40]))
+    paths = g.generate_random_walks(cx, m=N, seed=int(rs.randint(1 << 20)))
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=int(rs.randint(1 << 20)))
+    N = len(paths)
+    last = np.asarray(last[:N])
+    D = sc.max_degree
+    y = so.onehot_targets(np.asarray(choice[:N]), D)
+    hidden = int(rs.choice([8, 16, 32]))
+    k = 7 if model == "bunch" else 3
+    layers = [(k, hidden)] * int(rs.choice([2, 3]))
+    bs = max(2, N // 2)
+    train_mask = (rs.rand(N) < 0.8).astype(int)
+    train_mask[:2] = 1
+    wd = 5e-5
+    shifts, operand, _ = te.setup_from_complex(sc, model)
+    inputs = [operand, last, flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-3, bs, wd, verbose=False)
+    net.setup(te.MODEL_FUNCS[model], layers, shifts, inputs, y, None, train_mask, model_type=model)
+    for w in net.weights:
+        w.mul_(15.0 if model != "ebli" else 3.0)                   # gradients well above rounding
+    w0 = [w.detach().cpu().numpy().astype(np.float64) for w in net.weights]
+    adam = so.Adam(w0, 1e-3)
+    X = flows.todense()[:N].astype(np.float64)
+    B1, B2 = (m.toarray() for m in g.incidence_matrices(cx))
+    nb, _ = so.neighborhoods(cx.edges, cx.n_nodes)
+    if model == "bunch":
+        S = [m.tocsr() for m in compute_shift_matrices(*g.incidence_matrices(cx))]
+        grad = lambda w, bm: so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, bm, wd)[1]
+    else:
+        sh = so.scone_shifts(B1, B2) if model == "scone" else so.ebli_shifts(B1, B2)
+        Bc = so.make_Bconds(B1, nb)
+        act = "tanh" if model == "scone" else "leaky_relu"
+        grad = lambda w, bm: so.scone_loss_and_grad(w, sh[0], sh[1], Bc, last, X, y, bm, wd, act)[1]
+    for i in range(3):
+        bm = np.array([1] * bs + [0] * (N - bs))
+        rs.shuffle(bm)
+        bm = np.logical_and(bm, train_mask).astype(int)
+        if bm.sum() == 0:
+            bm[0] = 1
+        net._step = i
+        net.grad_step(inputs, y, bm)
+        adam.update(i, grad(adam.x, bm))
+        for a, b in zip(net.weights, adam.x):
+            assert _maxdiff(a.cpu().numpy(), b) <= 5e-6, "%s %s step %d" % (model, layers, i)
