@@ -1135,14 +1135,17 @@ class BunchPlan:
         self.n_edges = int(self.sizes[1])
         dev = [s.device_csr() for s in shifts]
         hints = self.layout.block_starts
+        # a level without simplices (a complex without faces: B2 has no columns, BMM:71-135 still yields the seven shapes) carries
+        # nothing: its shifts are empty operators, its tensors have no rows -- the shifts that touch it are left out altogether
+        self._live = [self.sizes[BUNCH_SRC[k]] > 0 and self.sizes[BUNCH_DST[k]] > 0 for k in range(7)]
         self.term_fwd = [ConvOp(self.sizes[BUNCH_DST[k]], [{"mats": [dev[k]], "identity": False,
                                                            "n_cols": self.sizes[BUNCH_SRC[k]]}], hints[BUNCH_DST[k]])
-                         for k in range(7)]
+                         if self._live[k] else None for k in range(7)]
         self.term_bwd = [ConvOp(self.sizes[BUNCH_SRC[k]], [{"mats": [dev[k].T.tocsr()], "identity": False,
                                                            "n_cols": self.sizes[BUNCH_DST[k]]}], hints[BUNCH_SRC[k]])
-                         for k in range(7)]
-        self.fwd_slots = [[k for k in range(7) if BUNCH_DST[k] == lvl] for lvl in range(3)]
-        self.bwd_slots = [[k for k in range(7) if BUNCH_SRC[k] == lvl] for lvl in range(3)]
+                         if self._live[k] else None for k in range(7)]
+        self.fwd_slots = [[k for k in range(7) if BUNCH_DST[k] == lvl and self._live[k]] for lvl in range(3)]
+        self.bwd_slots = [[k for k in range(7) if BUNCH_SRC[k] == lvl and self._live[k]] for lvl in range(3)]
         self._dev_csr = dev
         self._generic = None
         self._terms = None                              # fused-layer operators (forward, transposed), built on first use
@@ -1169,6 +1172,8 @@ class BunchPlan:
         """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer.
         None when the plan builder cannot hold the complex (SCN_ERR_UNSUPPORTED: a single concatenated row with more than
         104 distinct sources, e.g. a hub node) -- the per-shift path then carries every layer, forward AND backward."""
+        if self._terms is None and not all(self._live):
+            self._terms = False                          # an empty level: the per-shift path (nothing to fuse across three levels)
         if self._terms is None:
             dev = self._dev_csr
             try:
@@ -1248,7 +1253,7 @@ class BunchPlan:
         need[L][0] = True
         for i in range(L - 1, 0, -1):
             for k in range(7):
-                if need[i + 1][BUNCH_DST[k]]:
+                if self._live[k] and need[i + 1][BUNCH_DST[k]]:
                     need[i][BUNCH_SRC[k]] = True
         states, zeros = [cur], [zero]
         first_g = {}
@@ -1324,7 +1329,7 @@ class BunchPlan:
     # (u_k^+- = sum_p (S_k g^+-)[p] dZ2[p][:], scn_dense_terms_backward) from which both layers' weight gradients follow by
     # scn_fold1_backward.  Same sums as TE:183-195 in another association order; relu'(0) = 0 as everywhere here.
     def _fold_ok(self, x, weights, L, ns):
-        if not (FOLD_BUNCH and FUSE_BUNCH and L >= 3 and x.shape[3] == 1 and self._blocked_ok(ns, 1)):
+        if not (FOLD_BUNCH and FUSE_BUNCH and L >= 3 and x.shape[3] == 1 and self._blocked_ok(ns, 1) and all(self._live)):
             return False
         c1 = {weights[k].shape[1] for k in range(7)}
         c2 = {weights[7 + k].shape[1] for k in range(7)}

@@ -190,3 +190,56 @@ def test_random_trainer_steps_match_oracle_adam(seed):
         adam.update(i, grad(adam.x, bm))
         for a, b in zip(net.weights, adam.x):
             assert _maxdiff(a.cpu().numpy(), b) <= 5e-6, "%s %s step %d" % (model, layers, i)
+
+
+@pytest.mark.parametrize("model", ["scone", "ebli", "bunch"])
+def test_complex_without_faces(model):
+    """A grid graph: edges, no triangle at all (B2 has no columns, L_up = 0, the Bunch face level is empty) -- the degenerate
+    input of TE:240-257 / BMM:71-135.  Forward, loss and every weight gradient against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    n = 7
+    idx = np.arange(n * n).reshape(n, n)
+    edges = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()], 1), np.stack([idx[:-1].ravel(), idx[1:].ravel()], 1)])
+    edges = np.unique(np.sort(edges, axis=1), axis=0)
+    xy = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2) / (n - 1.0)
+    cx = g.Complex(n_nodes=n * n, edges=edges, faces=np.zeros((0, 3), np.int64), coords=xy)
+    sc = SimplicialComplex(cx)
+    rs = np.random.RandomState(5)
+    N = 6
+    X = np.zeros((N, len(edges), 1))
+    for i in range(N):
+        sel = rs.choice(len(edges), 5, replace=False)
+        X[i, sel, 0] = rs.choice([-1.0, 1.0], 5)
+    last = rs.randint(0, n * n, N)
+    D = sc.max_degree
+    nb, D2 = so.neighborhoods(edges, n * n)
+    assert D == D2 == 4
+    choice = np.array([rs.randint(0, max(1, int((nb[v] >= 0).sum()))) for v in last])
+    y = so.onehot_targets(choice, D)
+    mask = np.ones(N, int)
+    B1, B2 = (m.toarray() for m in g.incidence_matrices(cx))
+    assert B2.shape == (len(edges), 0)
+    if model == "bunch":
+        pytest.importorskip("scipy")
+        from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+        w = [0.4 * rs.randn(*s) for s in so.weight_shapes(1, [(7, 16)] * 2, 1, "bunch")]
+        S = [m.tocsr() for m in compute_shift_matrices(*g.incidence_matrices(cx))]
+        ref_loss, ref_g = so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, mask, 0.0)
+        shifts, operand, _ = te.setup_from_complex(sc, "bunch")
+    else:
+        w = [(0.3 if model == "scone" else 0.05) * rs.randn(*s) for s in so.weight_shapes(1, [(3, 16)] * 2, 1)]
+        sh = so.scone_shifts(B1, B2) if model == "scone" else so.ebli_shifts(B1, B2)
+        act = "tanh" if model == "scone" else "leaky_relu"
+        ref_loss, ref_g = so.scone_loss_and_grad(w, sh[0], sh[1], so.make_Bconds(B1, nb), last, X, y, mask, 0.0, act)
+        shifts, operand, _ = te.setup_from_complex(sc, model)
+    wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+    out = te.MODEL_FUNCS[model](wt, *shifts, operand, last, X)
+    loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / N
+    loss.backward()
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for k in range(len(w)):
+        assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
