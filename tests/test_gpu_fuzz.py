@@ -243,3 +243,52 @@ def test_complex_without_faces(model):
     assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for k in range(len(w)):
         assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "weight %d" % k
+
+
+@pytest.mark.parametrize("model", ["scone", "ebli", "bunch"])
+@pytest.mark.parametrize("shape", ["triangle", "two_triangles", "path"])
+def test_tiny_complexes(model, shape):
+    """Complexes smaller than one wave's rows: a single triangle (V = E = 3, F = 1), two triangles sharing an edge (4 / 5 / 2) and
+    a three-edge path without faces -- one trajectory and three, every model."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    if shape == "triangle":
+        edges, faces, xy = [[0, 1], [0, 2], [1, 2]], [[0, 1, 2]], [[0, 0], [1, 0], [0, 1]]
+    elif shape == "two_triangles":
+        edges, faces, xy = [[0, 1], [0, 2], [1, 2], [1, 3], [2, 3]], [[0, 1, 2], [1, 2, 3]], [[0, 0], [1, 0], [0, 1], [1, 1]]
+    else:
+        edges, faces, xy = [[0, 1], [1, 2], [2, 3]], np.zeros((0, 3), np.int64), [[0, 0], [0.3, 0], [0.6, 0], [1, 0]]
+    cx = g.Complex(n_nodes=len(xy), edges=np.asarray(edges, np.int64), faces=np.asarray(faces, np.int64).reshape(-1, 3),
+                   coords=np.asarray(xy, float))
+    sc = SimplicialComplex(cx)
+    E, V = len(edges), len(xy)
+    rs = np.random.RandomState(len(shape))
+    for N in (1, 3):
+        X = rs.choice([-1.0, 0.0, 1.0], size=(N, E, 1))
+        last = rs.randint(0, V, N)
+        nb, D = so.neighborhoods(cx.edges, V)
+        choice = np.array([rs.randint(0, max(1, int((nb[v] >= 0).sum()))) for v in last])
+        y = so.onehot_targets(choice, D)
+        B1, B2 = (m.toarray() for m in g.incidence_matrices(cx))
+        if model == "bunch":
+            w = [0.5 * rs.randn(*s) for s in so.weight_shapes(1, [(7, 8)] * 2, 1, "bunch")]
+            S = [m.tocsr() for m in compute_shift_matrices(*g.incidence_matrices(cx))]
+            ref_loss, ref_g = so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, np.ones(N, int), 0.0)
+            shifts, operand, _ = te.setup_from_complex(sc, "bunch")
+        else:
+            w = [(0.5 if model == "scone" else 0.1) * rs.randn(*s) for s in so.weight_shapes(1, [(3, 16)] * 2, 1)]
+            sh = so.scone_shifts(B1, B2) if model == "scone" else so.ebli_shifts(B1, B2)
+            act = "tanh" if model == "scone" else "leaky_relu"
+            ref_loss, ref_g = so.scone_loss_and_grad(w, sh[0], sh[1], so.make_Bconds(B1, nb), last, X, y, np.ones(N, int), 0.0, act)
+            shifts, operand, _ = te.setup_from_complex(sc, model)
+        wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
+        out = te.MODEL_FUNCS[model](wt, *shifts, operand, last, X)
+        loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / N
+        loss.backward()
+        assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss)), (shape, N)
+        for k in range(len(w)):
+            assert _maxdiff(wt[k].grad.cpu().numpy(), ref_g[k]) <= TOL, "%s N=%d weight %d" % (shape, N, k)
