@@ -64,12 +64,17 @@ def test_random_case_matches_oracle(seed, model):
         ref_out = so.bunch_forward(w, S, sc.nbrhoods, last, X)
         shifts, operand, _ = te.setup_from_complex(sc, "bunch")
     else:
-        sh = so.scone_shifts(B1, B2) if model == "scone" else so.ebli_shifts(B1, B2)
+        # every other case under random edge-orientation flips (-flip_edges, TE:214-219: F L F, B1 F, X F)
+        flips = rs.choice([1.0, -1.0], size=cx.n_edges, p=[0.8, 0.2]) if seed % 2 else None
+        F = np.diag(flips) if flips is not None else None
+        sh = so.scone_shifts(B1, B2, F) if model == "scone" else so.ebli_shifts(B1, B2, F)
         act = "tanh" if model == "scone" else "leaky_relu"
-        Bc = so.make_Bconds(B1, nb)
-        ref_loss, ref_g = so.scone_loss_and_grad(w, sh[0], sh[1], Bc, last, X, y, mask, 0.0, act)
-        ref_out = so.scone_forward(w, sh[0], sh[1], Bc, last, X, act)
-        shifts, operand, _ = te.setup_from_complex(sc, model)
+        Bc = so.make_Bconds(B1, nb, F)
+        Xf = X * flips[None, :, None] if flips is not None else X
+        ref_loss, ref_g = so.scone_loss_and_grad(w, sh[0], sh[1], Bc, last, Xf, y, mask, 0.0, act)
+        ref_out = so.scone_forward(w, sh[0], sh[1], Bc, last, Xf, act)
+        shifts, operand, _ = te.setup_from_complex(sc, model, flips=flips)
+        X = te.apply_flips(X, flips)
     wt = [torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True) for a in w]
     out = te.MODEL_FUNCS[model](wt, *shifts, operand, last, X)
     m = torch.as_tensor(mask, device="cuda").bool()
