@@ -348,3 +348,68 @@ def test_saturating_and_large_activations(cfg1, model, scale, gtol):
         gk = wt[k].grad.cpu().numpy().astype(np.float64)
         assert np.isfinite(gk).all()
         assert np.abs(gk - ref_g[k]).max() <= gtol * max(1.0, gmax), "weight %d: %g of %g" % (k, np.abs(gk - ref_g[k]).max(), gmax)
+
+
+@pytest.mark.parametrize("model,hidden", [("scone", 32), ("scone", 16), ("bunch", 32), ("ebli", 8)])
+def test_ragged_micro_batches(monkeypatch, model, hidden):
+    """A batch cut into several micro-batches with a ragged last one (27 trajectories as 8 + 8 + 8 + 3, the last slab half padding):
+    the accumulated loss and weight gradients of Scone_GCN.grad_step_staged equal the one-micro-batch result (summation order) and
+    the oracle's (STM:42-56: one mean over the whole batch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.bunch_model_matrices import compute_shift_matrices
+    cx = g.random_SC_graph(2000)
+    sc = SimplicialComplex(cx)
+    N = 27
+    paths = g.generate_random_walks(cx, m=N, seed=9, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=4)
+    N = len(paths)
+    last = np.asarray(last[:N])
+    y = so.onehot_targets(np.asarray(choice[:N]), sc.max_degree)
+    k = 7 if model == "bunch" else 3
+    shifts, operand, _ = te.setup_from_complex(sc, model)
+    inputs = [operand, last, flows]
+    res = {}
+    real = ops.micro_batch_size
+    for name, mb in (("one", None), ("ragged", 8)):
+        if mb:
+            monkeypatch.setattr(ops, "micro_batch_size", lambda *a, **kw: mb)
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-3, N, 0.0, verbose=False)
+        net.setup(te.MODEL_FUNCS[model], [(k, hidden)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type=model)
+        for w in net.weights:
+            w.mul_(15.0 if model != "ebli" else 3.0)
+        staged = net.stage(inputs, y, np.arange(N))
+        assert len(staged) == (1 if mb is None else 4)
+        loss = float(net.grad_step_staged(inputs, staged, N, apply=False))
+        res[name] = (loss, [t.detach().cpu().numpy().astype(np.float64) for t in net._grads],
+                     [w.detach().cpu().numpy().astype(np.float64) for w in net.weights])
+        monkeypatch.setattr(ops, "micro_batch_size", real)
+    gmax = max(float(np.abs(a).max()) for a in res["one"][1])
+    assert abs(res["one"][0] - res["ragged"][0]) <= 1e-6 * max(1.0, abs(res["one"][0]))
+    for a, b in zip(res["one"][1], res["ragged"][1]):
+        assert np.abs(a - b).max() <= 2e-6 * gmax
+    w = res["one"][2]
+    X = flows.todense()[:N].astype(np.float64)
+    B1, B2 = g.incidence_matrices(cx)
+    if model == "bunch":
+        S = [m.tocsr() for m in compute_shift_matrices(B1, B2)]
+        ref_loss, ref_g = so.bunch_loss_and_grad(w, S, sc.nbrhoods, last, X, y, np.ones(N, int), 0.0)
+    else:
+        import scipy.sparse as sp
+        L_lo, L_up = (B1.T @ B1).tocsr(), (B2 @ B2.T).tocsr()
+        if model == "ebli":
+            L1 = (L_lo + L_up).tocsr()
+            L_lo, L_up = L1, (L1 @ L1).tocsr()
+        B1x = sp.vstack([B1, sp.csr_matrix((1, B1.shape[1]))]).tocsr()
+        Bc = lambda v: B1x[sc.nbrhoods[v]].toarray()
+        ref_loss, ref_g = so.scone_loss_and_grad(w, L_lo, L_up, Bc, last, X, y, np.ones(N, int), 0.0,
+                                                 "tanh" if model == "scone" else "leaky_relu")
+    assert abs(res["ragged"][0] - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    for a, b in zip(res["ragged"][1], ref_g):
+        assert _maxdiff(a, b) <= TOL
