@@ -597,6 +597,11 @@ def main():
         sc2 = SimplicialComplex(cx2)
         configs["configs[1]"] = side_config("BASELINE configs[1]: synthetic |E|~50k, hidden 16, batch 1024", "scone", cx2, sc2,
                                             16, 1024, 10, sync, traffic_section="configs[1]")
+        # configs[0]: the reference's own case (TE:86-90): 400-point complex (|E| = 1001), hidden 16, batch 100, resident on the device
+        cx0 = g.random_SC_graph(400)
+        configs["configs[0]"] = side_config("BASELINE configs[0]: synthetic_data_gen.py 400-point complex, 3-layer SCoNe hidden 16, batch 100 "
+                                            "(the reference's own problem size; its dense-faithful CPU restatement is cpu_baseline.dense_faithful_configs0)",
+                                            "scone", cx0, SimplicialComplex(cx0), 16, 100, 50, sync)
         # configs[2]: ocean drifters, full training batch (the trajectories of tests/golden/buoy.npz)
         bpath = os.path.join(ROOT, "tests", "golden", "buoy.npz")
         if os.path.exists(bpath):
