@@ -413,3 +413,38 @@ def test_ragged_micro_batches(monkeypatch, model, hidden):
     assert abs(res["ragged"][0] - ref_loss) <= TOL * max(1.0, abs(ref_loss))
     for a, b in zip(res["ragged"][1], ref_g):
         assert _maxdiff(a, b) <= TOL
+
+
+@pytest.mark.parametrize("model,hidden", [("scone", 32), ("scone", 16), ("ebli", 32), ("bunch", 32), ("scone", 64)])
+def test_gradient_step_is_bitwise_reproducible(model, hidden):
+    """Per-workgroup partials and fixed-order reductions: the same step twice gives the same loss and the same flat gradient
+    buffer BIT FOR BIT, for every model and for the 32-channel-block path (tools/determinism.py checks it at |E| = 1M)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(8000)
+    sc = SimplicialComplex(cx)
+    B = 40
+    paths = g.generate_random_walks(cx, m=B, seed=11, waypoint_pool=8, metric="euclid")
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=3)
+    B = len(paths)
+    y = so.onehot_targets(np.asarray(choice[:B]), sc.max_degree)
+    shifts, operand, _ = te.setup_from_complex(sc, model)
+    inputs = [operand, np.asarray(last[:B]), flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-3, B, 5e-5, verbose=False)
+    net.use_graph = False
+    net.setup(te.MODEL_FUNCS[model], [(7 if model == "bunch" else 3, hidden)] * 3, shifts, inputs, y, None, np.ones(B, int), model_type=model)
+    for w in net.weights:
+        w.mul_(10.0)
+    staged = net.stage(inputs, y, np.arange(B))
+    snaps = []
+    for _ in range(3):
+        loss = net.grad_step_staged(inputs, staged, B, apply=False).detach().clone()
+        snaps.append((loss, net._flat_g.detach().clone()))
+    assert float(snaps[0][1].abs().sum()) > 0
+    for loss, gsnap in snaps[1:]:
+        assert torch.equal(loss, snaps[0][0]) and torch.equal(gsnap, snaps[0][1])
