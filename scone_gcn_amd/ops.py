@@ -978,8 +978,14 @@ class SconePlan:
                                        _dev(grads[-1]), _stream()), "scn_readout_backward")
         return dz_top, key
 
+    SMALL_DZ_BYTES = 8 << 20      # below this a plain fill of the buffer is cheaper than walking the readout's rows again (small complexes)
+
     def _release_top(self, dz_top, key, last_dev):
         S, E, ns, C = key
+        if dz_top.numel() * 4 <= self.SMALL_DZ_BYTES:
+            dz_top.zero_()
+            self._dz_zero[key] = dz_top
+            return
         check(_lib.load().scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
                                                _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
                                                _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
