@@ -581,7 +581,7 @@ def main():
                                                   cx, sc, 32, 1024, 2, sync, traffic_section="bunch")
         configs["ebli"] = side_config("-model ebli (SNN), |E|~1M, hidden 32, batch 128", "ebli", cx, sc, 32, 128, 3, sync,
                                       traffic_section="ebli")
-        configs["ebli hidden 16"] = side_config("-model ebli (SNN), |E|~1M, hidden 16, batch 128 (S (S H) as two ring SpMMs + dense-term kernels)",
+        configs["ebli hidden 16"] = side_config("-model ebli (SNN), |E|~1M, hidden 16, batch 128 (ring SpMM + the power kernels on slab pairs)",
                                                 "ebli", cx, sc, 16, 128, 3, sync)
         # the reference's documented mixed-width stack (TE:51) on the same complex: runs on the hidden-32 kernels (promotion)
         configs["mixed widths"] = side_config("-hidden_layers [(3,32),(3,16)] (TE:51), |E|~1M, batch 128", "scone", cx, sc, 32, 128, 3,

@@ -213,7 +213,8 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
  * array); the caller forms y = S x (forward) or g1 = S^T dz (backward) with scn_spmm_dual and these calls do the rest:
  *   forward :  out = act(x W[0] + y W[1] + (S y) W[2])                                    x0 = x, x = y below
  *   backward:  dx = (dz W[0]^T + g1 W[1]^T + (S^T g1) W[2]^T) * act'(aux),  dW[k] += aux^T (dz | g1 | S^T g1)
- * All tensors [n_slabs][n_rows][ns][channels]; served for channels = 32 (SCN_ERR_UNSUPPORTED / workspace 0 otherwise). */
+ * All tensors [n_slabs][n_rows][ns][channels]; served for channels = 32 and 16 (16: two slabs per visit, like the plain layers;
+ * SCN_ERR_UNSUPPORTED / workspace 0 otherwise). */
 int scn_conv_forward_power(scn_conv_t conv, int32_t n_slabs, int32_t ns, const float* x0, const float* x,
                            const float* const* W, int32_t channels, int32_t act, float* out, void* stream);
 size_t scn_conv_backward_power_workspace(scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t channels);

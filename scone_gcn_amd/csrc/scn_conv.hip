@@ -29,10 +29,10 @@ int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz,
 bool blocked_spmm_supported(const scn_conv_s* c, int k);
 bool blocked_power_supported(const scn_conv_s* c, int ns, int ch);
 size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
-int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const float* x, const float* const* W, int act,
+int blocked_power_forward(scn_conv_s* c, int n_slabs, const float* x0, const float* x, const float* const* W, int ch, int act,
                           float* out, hipStream_t st);
 int blocked_power_backward(scn_conv_s* c, int n_slabs, const float* dz, const float* g1, const float* const* W,
-                           const float* aux, int act, float* dx, float* const* dW, void* ws, hipStream_t st);
+                           const float* aux, int ch, int act, float* dx, float* const* dW, void* ws, hipStream_t st);
 bool blocked_backward_first_supported(const scn_conv_s* c, int ns, int ch);
 size_t blocked_backward_first_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
 int blocked_backward_first(scn_conv_s* c, int n_slabs, const float* dz, const float* const* W, const float* aux, int ch, int act,
@@ -599,7 +599,7 @@ int scn_conv_forward_power(scn_conv_t c, int32_t n_slabs, int32_t ns, const floa
     if (!c || !x0 || !x || !W || !W[0] || !W[1] || !W[2] || !out) return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     if (!blocked_power_supported(c, ns, channels)) return SCN_ERR_UNSUPPORTED;
-    return blocked_power_forward(c, n_slabs, x0, x, W, act, out, (hipStream_t)stream);
+    return blocked_power_forward(c, n_slabs, x0, x, W, channels, act, out, (hipStream_t)stream);
 }
 
 size_t scn_conv_backward_power_workspace(scn_conv_t c, int32_t n_slabs, int32_t ns, int32_t channels) {
@@ -616,7 +616,7 @@ int scn_conv_backward_power(scn_conv_t c, int32_t n_slabs, int32_t ns, const flo
     if (n_slabs <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
     if (!blocked_power_supported(c, ns, channels)) return SCN_ERR_UNSUPPORTED;
     if (workspace_bytes < scn_conv_backward_power_workspace(c, n_slabs, ns, channels)) return SCN_ERR_WORKSPACE;
-    return blocked_power_backward(c, n_slabs, dz, g1, W, aux, act, dx, dW, workspace, (hipStream_t)stream);
+    return blocked_power_backward(c, n_slabs, dz, g1, W, aux, channels, act, dx, dW, workspace, (hipStream_t)stream);
 }
 
 int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,

@@ -146,9 +146,11 @@ def test_fused_first_backward_on_dense_slabs_at_one_million_edges(scone_big, C, 
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
-def test_ebli_power_kernels_on_dense_slabs_at_one_million_edges(big_complex):
+@pytest.mark.parametrize("C,S", [(32, 2), (16, 3)])
+def test_ebli_power_kernels_on_dense_slabs_at_one_million_edges(big_complex, C, S):
     """scn_conv_forward_power / scn_conv_backward_power (Ebli on large complexes, TE:161-167 with L1^2 never formed):
-    out = act(x0 W0 + x W1 + (L1 x) W2) and its gradient given g1 = L1^T dz, dense random slabs, C = 32."""
+    out = act(x0 W0 + x W1 + (L1 x) W2) and its gradient given g1 = L1^T dz, dense random slabs, C = 32 and C = 16 (the
+    slab-pair form; three slabs: one pair and a lone last slab)."""
     from scone_gcn_amd import ops, trajectory_experiments as te
     cx, sc = big_complex
     shifts, readout, _ = te.setup_from_complex(sc, "ebli")
@@ -156,7 +158,7 @@ def test_ebli_power_kernels_on_dense_slabs_at_one_million_edges(big_complex):
     assert isinstance(plan, ops.PowerPlan)
     L1 = shifts[0].device_csr().astype(np.float64)
     aL1 = abs(L1)
-    E, C, S = cx.n_edges, 32, 2
+    E = cx.n_edges
     rs = np.random.RandomState(5)
     x0 = rs.randn(S, E, 4, C).astype(np.float32)
     x = rs.randn(S, E, 4, C).astype(np.float32)

@@ -708,7 +708,7 @@ def test_zero_skipping_modes_match_the_dense_step(model, mode, hidden):
             assert float(t.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("hidden", [8, 32])
+@pytest.mark.parametrize("hidden", [8, 16, 32])
 def test_ebli_composed_plan_matches_fused_operator(cfg1, sc1, hidden):
     """PowerPlan (S (S H) on the blocked SpMM + dense term kernels; what Ebli uses when L1^2 outgrows the block plan) against
     the plan that applies the stored L1^2: same log-probabilities, same gradients."""
