@@ -344,6 +344,28 @@ int scn_plan_refine_order(int32_t n, const int32_t* rowptr, const int32_t* col, 
 int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, const float* val1, int32_t identity,
                           const uint8_t* block_start, int64_t* out4);
 
+/* The gradient step of a scone_func model (TE:137-152 + the loss of STM:42-56) on a SMALL complex in ONE launch -- the reference's own
+ * problem sizes (TE:86-90: |E| = 1001, batch 100).  One workgroup per trajectory keeps that trajectory's activations in LDS through
+ * every layer, the readout, the cross-entropy and the whole backward (csrc/scn_small.hip); a second launch sums the per-trajectory
+ * weight-gradient partials in trajectory order (bitwise reproducible).  Equivalent to
+ *   scn_conv_forward_first, scn_conv_forward x (L - 1), scn_readout_forward, scn_masked_ce, scn_readout_backward,
+ *   scn_conv_backward x (L - 2), scn_conv_backward_fused_first
+ * on the same buffers:  dW[k] += d/dW[k] of  scale * sum_n <logp_n, y_n>,   loss[0] += scale * sum_n <logp_n, y_n>
+ * (overwrite != 0: "=" instead of "+=" for both -- the first micro-batch of a step then needs no zeroing launch before it).
+ *   conv / conv_t : the operator (identity + S_lower + S_upper on a shared pattern) and its transpose (the same handle for symmetric shifts)
+ *   x [n_slabs][n_edges][ns][1], last_nodes [n_slabs*ns], y [n_slabs*ns][max_deg] (zero rows = padding trajectories)
+ *   W / dW : 3 * n_layers + 1 matrices in the reference's order (TE:139-152), first layer (1, hidden), last (hidden, 1)
+ *   max_items : caller's bound on sum_d (incident edges of neighbour d) over the neighbourhood of any last node
+ * Served (scn_small_step_supported): hidden = 16, 2 <= n_layers <= 6, max_deg <= 64, max_items <= 512 and 128 * |E| + 64 KB of LDS
+ * within 160 KB (|E| <= ~1100); SCN_ERR_UNSUPPORTED otherwise -- the caller then runs the layer-by-layer entry points. */
+int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, int32_t max_deg, int32_t max_items);
+size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers);
+int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                   const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                   int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                   const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* Masked cross-entropy of one micro-batch (the data term of STM:54 and its gradient w.r.t. the log-probabilities):
  *   d_logp[i] = y[i] * scale   (scale = -1 / number of trajectories in the GLOBAL batch; padding rows have y = 0)
  *   loss[0]  += sum_i logp[i] * d_logp[i]    (fp64 accumulator on the device, fixed summation order)

@@ -147,5 +147,6 @@ struct scn_conv_s {
     int32_t slot_kind[SCN_MAX_SLOTS] = {0, 0, 0, 0};   // 0 identity, 1 val0, 2 val1
     scn::BlockPlan plan;
     scn::TermsPlan terms;
+    void* small_pack = nullptr;         // (col, val0, val1, 0) per entry for scn_small_step, built on first use (owned through plan.allocs)
     std::vector<uint8_t> block_start;   // optional layout hint: 1 where a block of the plan must start (see scn_plan_refine_order)
 };

@@ -1,0 +1,670 @@
+// The whole gradient step of a SCoNe model on a SMALL complex in one launch (scn_small_step).
+//
+// The reference's own problem sizes (TE:86-90: |E| = 1001, batch 100; the drifter data set: |E| = 320) are launch-bound on the
+// layer-by-layer kernels: five fused conv launches, readout, cross-entropy and their reductions are ~17 launches of 4-18 us
+// each per optimiser step, and what every launch does is a chain of a few dependent L2 round trips.
+// Trajectories do not interact (TE:256 vmap) -- only the weight gradient sums over them -- and on a complex this small ONE
+// trajectory's activation tensor (|E| x 16 floats) fits the LDS of a CU.  So: one workgroup per trajectory runs every layer,
+// the readout, the cross-entropy and the whole backward on LDS-resident activations, with workgroup barriers between layers and
+// no halo, no staging and no inter-workgroup dependency; the per-trajectory weight-gradient partials are then summed in a fixed
+// order by a second, tiny launch.
+//
+//   lane (r = lane & 15, q = lane >> 4) of a wave owns row 16 t + r of tile t and the channel quad 4 q .. 4 q + 3: it gathers
+//   sum_j S[row][col_j] * H[col_j][quad] with 16-byte LDS reads, and that register layout IS the B operand of
+//   v_mfma_f32_16x16x4_f32 (K = channel, N = row), whose D tile comes back in the same (row, quad) layout: out^T = W^T z^T for
+//   the forward, dX^T = W G^T for the backward.  The weight gradient dW = aux^T G needs G with the rows along K: an MFMA against
+//   the identity transposes it in registers (exact: products with 1.0 and 0.0).  Everything is fp32 FMA arithmetic -- no split.
+//
+// Served: hidden width 16, one input channel, >= 2 layers, |E| small enough for two activation buffers in 160 KB of LDS.
+#include "scn_internal.h"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace scn {
+
+constexpr int SM_THREADS = 512, SM_WAVES = 8, SM_C = 16;      // eight waves: 256 registers per lane, room for a row's entries in flight
+constexpr int SM_MAX_LAYERS = 6;
+constexpr int SM_ITEMS = 512, SM_MAXD = 64;     // readout item list / neighbourhood width one wave handles (as scn_readout.hip)
+constexpr int SM_LAYER_W = 3 * SM_C * SM_C;     // 768 weights per layer
+constexpr int SM_CH = 12;                       // operator entries of a row requested in one go (a round trip to L2 per row otherwise)
+constexpr int SM_RO_PRE = 8;                    // readout items per neighbour slot requested at kernel start
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- diagnostic build only (-DSCN_STAMPS, tools/build_stamps.sh): wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries
+#ifdef SCN_STAMPS
+__device__ unsigned long long g_small_stamps[16];
+#define SM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[k] = wall_clock64(); } while (0)
+#else
+#define SM_STAMP(k)
+#endif
+
+struct SmallArgs {
+    int32_t n_edges, ns, n_layers, act, max_deg, same_t;
+    const int32_t* rowptr;   const float4* ent;      // operator rows: (col, val_lower, val_upper, 0) per entry
+    const int32_t* rowptr_t; const float4* ent_t;    // its transpose (the same arrays for symmetric shifts: same_t)
+    const float* x;                                   // [S][E][ns]
+    const int32_t* last_nodes;                        // [S * ns]
+    const float* y;                                   // [S * ns][max_deg]
+    float scale;
+    const int32_t* nbr; const int32_t* inc_ptr; const int32_t* inc_edge; const float* inc_sign;
+    const float* W[3 * SM_MAX_LAYERS + 1];
+    float* hs;                                        // [n_layers - 1][N][E][16]  saved activations H_1 .. H_{L-1}
+    float* ys;                                        // [N][E][4]                 (x, S_lo x, S_up x, 0)
+    float* partial;                                   // [N][PW]                   per-trajectory weight-gradient partials
+    double* loss_part;                                // [N]
+};
+
+__host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C + (n_layers - 1) * SM_LAYER_W + SM_C; }
+
+// LDS: two activation buffers, one layer's weights, readout scratch, the row pointers, reduction scratch
+struct SmallLds {
+    int epad;
+    size_t off_w, off_misc, off_rp, off_red, total;
+};
+__host__ __device__ static inline SmallLds small_lds(int n_edges, bool same_t) {
+    SmallLds L;
+    L.epad = (n_edges + 15) & ~15;
+    const size_t buf = (size_t)L.epad * SM_C * 4;
+    L.off_w = 2 * buf;
+    L.off_misc = L.off_w + SM_LAYER_W * 4;
+    // misc: lgs[64] dl[64] wlast[16] d_ptr[80] it_e[512] it_s[512] it_d[512] bh[64*16] dwf[8*48]
+    const size_t misc = (64 + 64 + 16 + 80 + 3 * SM_ITEMS + 64 * SM_C + SM_WAVES * 48) * 4;
+    L.off_rp = L.off_misc + misc;
+    const size_t rp = ((size_t)(n_edges + 1) * 4 + 15) / 16 * 16;
+    L.off_red = L.off_rp + (same_t ? rp : 2 * rp);
+    const size_t red = (size_t)SM_WAVES * SM_LAYER_W * 4;
+    L.total = L.off_red + (buf >= red ? 0 : red);            // big buffers: the reduction overlays the dead input buffer
+    return L;
+}
+
+__device__ __forceinline__ float sm_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sm_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int sm_excl_scan(int v, int lane) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
+// The first SM_CH entries of a row, requested together (index 0 stands in for entries past the row's end: always readable).
+struct SmChunk { float4 e[SM_CH]; };
+__device__ __forceinline__ void sm_request(const float4* __restrict__ ent, int j0, int j1, SmChunk& c) {
+#pragma unroll
+    for (int u = 0; u < SM_CH; ++u) c.e[u] = ent[j0 + u < j1 ? j0 + u : 0];
+}
+// gather of one row from its requested chunk (+ the rare tail read directly): lo += val_lower * H[col][quad], up += val_upper * ..
+__device__ __forceinline__ void sm_gather(const SmChunk& c, const float4* __restrict__ ent, int j0, int j1, const float* in, int q,
+                                          f32x4& lo, f32x4& up) {
+#pragma unroll
+    for (int u = 0; u < SM_CH; ++u) {
+        if (j0 + u < j1) {
+            const f32x4 d = *(const f32x4*)(in + (size_t)__float_as_int(c.e[u].x) * SM_C + 4 * q);
+            lo += c.e[u].y * d;
+            up += c.e[u].z * d;
+        }
+    }
+    for (int j = j0 + SM_CH; j < j1; j += 4) {
+        float4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = ent[j + u < j1 ? j + u : j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j + u < j1) {
+                const f32x4 d = *(const f32x4*)(in + (size_t)__float_as_int(e[u].x) * SM_C + 4 * q);
+                lo += e[u].y * d;
+                up += e[u].z * d;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int E = a.n_edges, L = a.n_layers, act = a.act;
+    const SmallLds lay = small_lds(E, a.same_t != 0);
+    const int epad = lay.epad, nt = epad >> 4;
+    float* const lds = (float*)smem;                            // (buffers are addressed as lds + offset: the compiler keeps LDS instructions)
+    const int bufsz = epad * SM_C;                              // floats per activation buffer: A at 0, B at bufsz
+    float* bufA = lds;
+    float* bufB = lds + bufsz;
+    float* Wl = (float*)(smem + lay.off_w);
+    float* misc = (float*)(smem + lay.off_misc);
+    float* lgs = misc;                       // [64]
+    float* dls = lgs + 64;                   // [64]
+    float* wlast = dls + 64;                 // [16]
+    int* d_ptr = (int*)(wlast + 16);         // [80]
+    int* it_e = d_ptr + 80;                  // [512]
+    float* it_s = (float*)(it_e + SM_ITEMS); // [512]
+    int* it_d = (int*)(it_s + SM_ITEMS);     // [512]
+    float* bh = (float*)(it_d + SM_ITEMS);   // [64][16]
+    float* dwf_red = bh + 64 * SM_C;         // [8][48]
+    int* rp = (int*)(smem + lay.off_rp);     // row pointers of the operator ...
+    int* rpt = a.same_t ? rp : rp + (((E + 1) + 3) & ~3);       // ... and of its transpose
+    const int n = blockIdx.x, s = n / a.ns, i = n - s * a.ns;
+    const int N = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int PW = small_pw(L);
+    float* my_partial = a.partial + (size_t)n * PW;
+
+    SM_STAMP(0);
+    // ---------------- requested up front, used much later: the readout's tables of this trajectory (wave 0), its targets
+    int ro_start = 0, ro_cnt = 0, ro_e[SM_RO_PRE];
+    float ro_s[SM_RO_PRE], ro_y = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_RO_PRE; ++j) { ro_e[j] = 0; ro_s[j] = 0.f; }
+    if (wave == 0 && lane < a.max_deg) {
+        const int vlast = a.last_nodes[n];
+        const int v = a.nbr[(size_t)vlast * a.max_deg + lane];
+        ro_y = a.y[(size_t)n * a.max_deg + lane];
+        if (v >= 0) {
+            ro_start = a.inc_ptr[v];
+            ro_cnt = a.inc_ptr[v + 1] - ro_start;
+        }
+#pragma unroll
+        for (int j = 0; j < SM_RO_PRE; ++j)
+            if (j < ro_cnt) {
+                ro_e[j] = a.inc_edge[ro_start + j];
+                ro_s[j] = a.inc_sign[ro_start + j];
+            }
+    }
+
+    // ---------------- layer 1 (one input channel): y = (x, S_lo x, S_up x), H_1 = act(y . W_1)
+    for (int e = tid; e < E; e += SM_THREADS) bufB[e] = a.x[((size_t)s * E + e) * a.ns + i];
+    for (int e = tid; e <= E; e += SM_THREADS) {
+        rp[e] = a.rowptr[e];
+        if (!a.same_t) rpt[e] = a.rowptr_t[e];
+    }
+    if (tid < 3 * SM_C) Wl[tid] = a.W[tid / SM_C][tid % SM_C];
+    if (tid < SM_C) wlast[tid] = a.W[3 * L][tid];
+    __syncthreads();
+    SM_STAMP(1);
+    float4* ylds = (float4*)(bufB + epad);                      // [epad] behind the staged x
+    float4* ysn = (float4*)a.ys + (size_t)n * E;
+    for (int r0 = 0; r0 < epad; r0 += 2 * SM_THREADS) {         // two rows per thread and trip: both rows' entries in flight together
+        const int ra = r0 + tid, rb = r0 + SM_THREADS + tid;
+        const int ja0 = ra < E ? rp[ra] : 0, ja1 = ra < E ? rp[ra + 1] : 0;
+        const int jb0 = rb < E ? rp[rb] : 0, jb1 = rb < E ? rp[rb + 1] : 0;
+        SmChunk ca, cb;
+        sm_request(a.ent, ja0, ja1, ca);
+        sm_request(a.ent, jb0, jb1, cb);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = half ? rb : ra, j0 = half ? jb0 : ja0, j1 = half ? jb1 : ja1;
+            const SmChunk& c = half ? cb : ca;
+            if (r >= epad) continue;
+            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < E) {
+                float lo = 0.f, up = 0.f;
+#pragma unroll
+                for (int u = 0; u < SM_CH; ++u)
+                    if (j0 + u < j1) {
+                        const float xv = bufB[__float_as_int(c.e[u].x)];
+                        lo = fmaf(c.e[u].y, xv, lo);
+                        up = fmaf(c.e[u].z, xv, up);
+                    }
+                for (int j = j0 + SM_CH; j < j1; ++j) {
+                    const float4 en = a.ent[j];
+                    const float xv = bufB[__float_as_int(en.x)];
+                    lo = fmaf(en.y, xv, lo);
+                    up = fmaf(en.z, xv, up);
+                }
+                yv = make_float4(bufB[r], lo, up, 0.f);
+                ysn[r] = yv;
+            }
+            ylds[r] = yv;
+        }
+    }
+    __syncthreads();
+    SM_STAMP(2);
+    float* hs_n = a.hs + (size_t)n * E * SM_C;                  // + layer * N * E * 16
+    const size_t hs_layer = (size_t)N * E * SM_C;
+    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {
+        const int r = idx >> 2, qq = idx & 3;
+        const float4 yv = ylds[r];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * qq + j;
+            const float z = yv.x * Wl[c] + yv.y * Wl[SM_C + c] + yv.z * Wl[2 * SM_C + c];
+            o[j] = r < E ? act_apply_fast(act, z) : 0.f;
+        }
+        *(f32x4*)(bufA + (size_t)r * SM_C + 4 * qq) = o;
+        if (r < E) *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * qq) = o;
+    }
+    __syncthreads();
+
+    SM_STAMP(3);
+    // ---------------- layers 2 .. L: out = act(H W_0 + (S_lo H) W_1 + (S_up H) W_2)
+    // a wave's tiles are wave, wave + 8, ..: while one is computed the entries of the next are on their way
+    auto row_range = [&](const int* rptr, int t, int& j0, int& j1) {
+        const int r = 16 * t + r16;
+        j0 = r < E ? rptr[r] : 0;
+        j1 = r < E ? rptr[r + 1] : 0;
+    };
+    int in_o = 0, out_o = bufsz;
+    for (int li = 1; li < L; ++li) {
+        const float* in = lds + in_o;
+        float* out = lds + out_o;
+        if (tid < SM_LAYER_W / 2) {
+            Wl[tid] = a.W[3 * li + tid / (SM_C * SM_C)][tid % (SM_C * SM_C)];
+            const int t2 = tid + SM_LAYER_W / 2;
+            Wl[t2] = a.W[3 * li + t2 / (SM_C * SM_C)][t2 % (SM_C * SM_C)];
+        }
+        SmChunk cur;
+        int j0, j1;
+        row_range(rp, wave < nt ? wave : 0, j0, j1);
+        sm_request(a.ent, j0, j1, cur);
+        __syncthreads();
+        float wa[3][4];                                          // A[m = c_out = r16][k = (s, q)] = W_g[4 q + s][r16]
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wa[g][u] = Wl[g * 256 + (4 * q + u) * SM_C + r16];
+        for (int t = wave; t < nt; t += SM_WAVES) {
+            SmChunk nxt;
+            int n0, n1;
+            row_range(rp, t + SM_WAVES < nt ? t + SM_WAVES : t, n0, n1);     // (the last tile requests itself again: straight-line code)
+            sm_request(a.ent, n0, n1, nxt);
+            const int r = 16 * t + r16;
+            const bool valid = r < E;
+            f32x4 zs = {0.f, 0.f, 0.f, 0.f}, zl = zs, zu = zs;
+            if (valid) zs = *(const f32x4*)(in + (size_t)r * SM_C + 4 * q);
+            sm_gather(cur, a.ent, j0, j1, in, q, zl, zu);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][u], zs[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][u], zl[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2][u], zu[u], acc, 0, 0, 0);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = valid ? act_apply_fast(act, acc[j]) : 0.f;
+            *(f32x4*)(out + (size_t)r * SM_C + 4 * q) = o;
+            if (valid && li < L - 1) *(f32x4*)(hs_n + li * hs_layer + (size_t)r * SM_C + 4 * q) = o;
+            cur = nxt; j0 = n0; j1 = n1;
+        }
+        __syncthreads();
+        SM_STAMP(3 + li);
+        const int tmp = in_o; in_o = out_o; out_o = tmp;
+    }
+    const float* H = lds + in_o;                                 // H_L
+    float* dz = lds + out_o;                                     // free buffer -> readout gradient
+
+    // ---------------- readout (TE:151-152, 298-303), cross-entropy (STM:54) and their gradient; wave 0 walks the item list
+    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) *(f32x4*)(dz + (size_t)idx * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    int total = 0;
+    if (wave == 0) {
+        const int off = sm_excl_scan(ro_cnt, lane);
+        total = __shfl(off + ro_cnt, 63, 64);
+        const bool overflow = total > SM_ITEMS;                  // (the host checks the bound; never index past the list)
+        if (overflow) total = 0;
+        if (lane < a.max_deg) d_ptr[lane] = overflow ? 0 : off;
+        if (lane == 0) d_ptr[a.max_deg] = total;
+        if (!overflow) {
+#pragma unroll
+            for (int j = 0; j < SM_RO_PRE; ++j)
+                if (j < ro_cnt) {
+                    it_e[off + j] = ro_e[j];
+                    it_s[off + j] = ro_s[j];
+                    it_d[off + j] = lane;
+                }
+            for (int j = SM_RO_PRE; j < ro_cnt; ++j) {
+                it_e[off + j] = a.inc_edge[ro_start + j];
+                it_s[off + j] = a.inc_sign[ro_start + j];
+                it_d[off + j] = lane;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
+        const int g = lane >> 4, cc = lane & 15;
+        const float wc = wlast[cc];
+        for (int d0 = 0; d0 < a.max_deg; d0 += 4) {
+            const int d = d0 + g;
+            float acc = 0.f;
+            if (d < a.max_deg) {
+                const int t0 = d_ptr[d], t1 = d_ptr[d + 1];
+                for (int t = t0; t < t1; ++t) acc = fmaf(it_s[t], H[(size_t)it_e[t] * SM_C + cc], acc);
+                bh[d * SM_C + cc] = acc;
+            }
+            float lg = d < a.max_deg ? acc * wc : 0.f;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+            if (cc == 0 && d < a.max_deg) lgs[d] = lg;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool live = lane < a.max_deg;
+        const float logit = live ? lgs[lane] : 0.f;
+        const float xm = live ? logit : -INFINITY;
+        const float m = sm_wave_max(xm);
+        const float se = sm_wave_sum(live ? expf(xm - m) : 0.f);
+        const float lp = logit - (m + logf(se));
+        const float gy = live ? ro_y * a.scale : 0.f;            // d loss / d logp
+        double lpart = live ? (double)lp * (double)gy : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lpart += __shfl_xor(lpart, o, 64);
+        if (lane == 0) a.loss_part[n] = overflow ? (double)NAN : lpart;
+        const float gs = sm_wave_sum(gy);
+        if (live) dls[lane] = gy - expf(lp) * gs;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // d w_last[c] = sum_d dl[d] * bh[d][c]: lane (g, c) sums the slots d = g, g + 4, ..; the four groups combine in a fixed order
+        float dwl = 0.f;
+        for (int d = g; d < a.max_deg; d += 4) dwl = fmaf(dls[d], bh[d * SM_C + cc], dwl);
+        dwl += __shfl_xor(dwl, 16, 64);
+        dwl += __shfl_xor(dwl, 32, 64);
+        if (lane < SM_C) my_partial[PW - SM_C + lane] = dwl;
+    }
+    __syncthreads();
+    SM_STAMP(9);
+    if (wave == 0) {                                             // dH_L[e][c] += sign * dl[d] * w_last[c]: an edge has two endpoints, so at most
+        const int g = lane >> 4, cc = lane & 15;                 // two addends meet in an entry -- the sum does not depend on their order
+        const float wc = wlast[cc];
+        const uint32_t dz_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)dz;
+        for (int t = g; t < total; t += 4) {
+            const uint32_t addr = dz_addr + (uint32_t)(it_e[t] * SM_C + cc) * 4u;
+            const float v = it_s[t] * dls[it_d[t]] * wc;
+            asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {     // dz_L = dH_L * act'(H_L)
+        f32x4 v = *(f32x4*)(dz + (size_t)idx * 4);
+        const f32x4 h = *(const f32x4*)(H + (size_t)idx * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(act, h[j]);
+        *(f32x4*)(dz + (size_t)idx * 4) = v;
+    }
+    __threadfence();                                             // the saved activations (hs, ys) are read back from here on
+    __syncthreads();
+    SM_STAMP(10);
+
+    // ---------------- backward of layers L .. 2: G = (dz, S_lo^T dz, S_up^T dz), dx = (sum_g G_g W_g^T) act'(H_{l-1}), dW_g = H_{l-1}^T G_g
+    { const int tmp = in_o; in_o = out_o; out_o = tmp; }       // in = dz_L, out = the buffer H_L is done with
+    const bool red_overlay = (size_t)epad * SM_C >= (size_t)SM_WAVES * SM_LAYER_W;
+    float idm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idm[u] = (4 * q + u == r16) ? 1.f : 0.f;
+    struct SmAux { f32x4 q; float t[4]; float4 y; };            // streamed operands of a tile: aux quad, aux with the rows along K, y
+    for (int li = L - 1; li >= 1; --li) {
+        const float* aux = hs_n + (size_t)(li - 1) * hs_layer;    // H_li: the input of layer li + 1
+        const float* in = lds + in_o;
+        float* out = lds + out_o;
+        auto request_aux = [&](int t, SmAux& x) {
+            const int r = 16 * t + r16;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                        // A[m = c = r16][k = (u, q)] = aux[row 16 t + 4 q + u][r16]
+                const int rr = 16 * t + 4 * q + u;
+                x.t[u] = aux[(size_t)(rr < E ? rr : 0) * SM_C + r16];
+            }
+            x.q = *(const f32x4*)(aux + (size_t)(r < E ? r : 0) * SM_C + 4 * q);
+            x.y = li == 1 ? ysn[r < E ? r : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (tid < SM_LAYER_W / 2) {
+            Wl[tid] = a.W[3 * li + tid / (SM_C * SM_C)][tid % (SM_C * SM_C)];
+            const int t2 = tid + SM_LAYER_W / 2;
+            Wl[t2] = a.W[3 * li + t2 / (SM_C * SM_C)][t2 % (SM_C * SM_C)];
+        }
+        SmChunk cur;
+        SmAux ax;
+        int j0, j1;
+        row_range(rpt, wave < nt ? wave : 0, j0, j1);
+        sm_request(a.ent_t, j0, j1, cur);
+        request_aux(wave < nt ? wave : 0, ax);
+        __syncthreads();
+        f32x4 wb[3];                                             // A[m = c = r16][k = (s, q)] = W_g[r16][4 q + s]
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wb[g] = *(const f32x4*)(Wl + g * 256 + r16 * SM_C + 4 * q);
+        f32x4 dWacc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) dWacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float dwf[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dwf[g][j] = 0.f;
+        for (int t = wave; t < nt; t += SM_WAVES) {
+            SmChunk nxt;
+            SmAux axn;
+            int n0, n1;
+            const int tn = t + SM_WAVES < nt ? t + SM_WAVES : t;
+            row_range(rpt, tn, n0, n1);
+            sm_request(a.ent_t, n0, n1, nxt);
+            request_aux(tn, axn);
+            const int r = 16 * t + r16;
+            const bool valid = r < E;
+            f32x4 G[3];
+            G[0] = G[1] = G[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (valid) G[0] = *(const f32x4*)(in + (size_t)r * SM_C + 4 * q);
+            sm_gather(cur, a.ent_t, j0, j1, in, q, G[1], G[2]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][u], G[0][u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][u], G[1][u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[2][u], G[2][u], acc, 0, 0, 0);
+            }
+            f32x4 dx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dx[j] = valid ? acc[j] * act_grad_from_output(act, ax.q[j]) : 0.f;
+            if (li > 1) {
+                *(f32x4*)(out + (size_t)r * SM_C + 4 * q) = dx;
+            } else {                                             // dW_1[g][c] += y[row][g] * dx[row][c]   (dx = 0 on rows past the end)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dwf[0][j] = fmaf(ax.y.x, dx[j], dwf[0][j]);
+                    dwf[1][j] = fmaf(ax.y.y, dx[j], dwf[1][j]);
+                    dwf[2][j] = fmaf(ax.y.z, dx[j], dwf[2][j]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 Gt = {0.f, 0.f, 0.f, 0.f};                 // G_g with the rows along K: lane holds rows 4 q + j of channel r16
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Gt = __builtin_amdgcn_mfma_f32_16x16x4f32(G[g][u], idm[u], Gt, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float at = 16 * t + 4 * q + u < E ? ax.t[u] : 0.f;
+                    dWacc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, Gt[u], dWacc[g], 0, 0, 0);
+                }
+            }
+            cur = nxt; ax = axn; j0 = n0; j1 = n1;
+        }
+        __syncthreads();                                         // every wave is done with `in`
+        float* red = red_overlay ? lds + in_o : (float*)(smem + lay.off_red);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave * SM_LAYER_W + g * 256 + (4 * q + j) * SM_C + r16] = dWacc[g][j];
+        if (li == 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = dwf[g][j];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                    if (r16 == 0) dwf_red[wave * 48 + g * SM_C + 4 * q + j] = v;
+                }
+        }
+        __syncthreads();
+        for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < SM_WAVES; ++w) sum += red[w * SM_LAYER_W + o];
+            my_partial[3 * SM_C + (li - 1) * SM_LAYER_W + o] = sum;
+        }
+        if (li == 1 && tid < 48) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < SM_WAVES; ++w) sum += dwf_red[w * 48 + tid];
+            my_partial[tid] = sum;
+        }
+        __syncthreads();
+        SM_STAMP(10 + (L - li));
+        const int tmp = in_o; in_o = out_o; out_o = tmp;
+    }
+}
+
+// dW[k] (+)= sum_n partial[n][...] (trajectories in a fixed order), loss (+)= sum_n loss_part[n].  One block per 16 outputs: thread
+// (output, group g of 16) sums trajectories g, g + 16, .. with every load independent, the groups combine in order.
+struct SmallReduce {
+    int32_t n_traj, pw, n_w, overwrite;
+    int32_t off[3 * SM_MAX_LAYERS + 2];
+    float* dW[3 * SM_MAX_LAYERS + 1];
+    const float* partial;
+    const double* loss_part;
+    double* loss;
+};
+__global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
+    __shared__ float part[256];
+    const int oo = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + oo;
+    float acc = 0.f;
+    if (o < a.pw)
+        for (int n = g; n < a.n_traj; n += 16) acc += a.partial[(size_t)n * a.pw + o];
+    part[g * 16 + oo] = acc;
+    __syncthreads();
+    if (g == 0 && o < a.pw) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += part[k * 16 + oo];
+        int k = 0;
+        while (k + 1 < a.n_w && o >= a.off[k + 1]) ++k;
+        float* d = a.dW[k] + (o - a.off[k]);
+        *d = a.overwrite ? sum : *d + sum;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        double accd = 0.0;
+        for (int n = threadIdx.x; n < a.n_traj; n += 64) accd += a.loss_part[n];
+#pragma unroll
+        for (int w = 32; w > 0; w >>= 1) accd += __shfl_xor(accd, w, 64);
+        if (threadIdx.x == 0) a.loss[0] = a.overwrite ? accd : a.loss[0] + accd;
+    }
+}
+
+static std::mutex g_pack_mutex;
+
+// (col, val_lower, val_upper, 0) per entry on the device, built on first use and owned by the handle
+static int ensure_pack(scn_conv_s* c, const float4** ent) {
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    if (c->small_pack) { *ent = (const float4*)c->small_pack; return SCN_OK; }
+    const Group& G = c->g[0];
+    std::vector<float4> h((size_t)std::max<int64_t>(G.nnz, 1));
+    for (int64_t j = 0; j < G.nnz; ++j) {
+        int32_t col = G.h_col[j];
+        float cf;
+        std::memcpy(&cf, &col, 4);
+        h[j] = make_float4(cf, G.h_val0[j], G.h_val1[j], 0.f);
+    }
+    void* d = nullptr;
+    SCN_HIP_TRY(hipMalloc(&d, h.size() * sizeof(float4)));
+    c->plan.allocs.push_back(d);
+    SCN_HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->small_pack = d;
+    *ent = (const float4*)d;
+    return SCN_OK;
+}
+
+static bool small_shape(const scn_conv_s* c) {
+    return c && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 2 && c->g[0].n_cols == c->n_rows;
+}
+
+}  // namespace scn
+
+using namespace scn;
+
+#ifdef SCN_STAMPS
+extern "C" int scn_debug_small_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(scn::g_small_stamps), 128) == hipSuccess ? 0 : -3;
+}
+#endif
+
+extern "C" {
+
+int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, int32_t max_deg, int32_t max_items) {
+    if (!small_shape(conv)) return 0;
+    if (n_layers < 2 || n_layers > SM_MAX_LAYERS || hidden != SM_C) return 0;
+    if (max_deg <= 0 || max_deg > SM_MAXD || max_items > SM_ITEMS) return 0;
+    return small_lds(conv->n_rows, false).total <= 160 * 1024 ? 1 : 0;
+}
+
+size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers) {
+    if (n_edges <= 0 || n_traj <= 0 || n_layers < 2 || n_layers > SM_MAX_LAYERS) return 0;
+    const size_t hs = (size_t)(n_layers - 1) * n_traj * n_edges * SM_C * 4;
+    const size_t ys = (size_t)n_traj * n_edges * 16;
+    const size_t part = ((size_t)n_traj * small_pw(n_layers) * 4 + 15) / 16 * 16;
+    return hs + ys + part + (size_t)n_traj * 8 + 256;
+}
+
+int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                   const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                   int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                   const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    if (!conv || !conv_t || !x || !last_nodes || !y || !nbr || !inc_ptr || !inc_edge || !inc_sign || !W || !dW || !loss || !workspace)
+        return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (!small_shape(conv_t) || conv_t->n_rows != conv->n_rows) return SCN_ERR_BAD_SHAPE;
+    if (!scn_small_step_supported(conv, n_layers, hidden, max_deg, max_items)) return SCN_ERR_UNSUPPORTED;
+    for (int k = 0; k < 3 * n_layers + 1; ++k)
+        if (!W[k] || !dW[k]) return SCN_ERR_BAD_ARG;
+    const int E = conv->n_rows, N = n_slabs * ns;
+    if (workspace_bytes < scn_small_step_workspace(E, N, n_layers)) return SCN_ERR_WORKSPACE;
+    SmallArgs a{};
+    a.n_edges = E; a.ns = ns; a.n_layers = n_layers; a.act = act; a.max_deg = max_deg;
+    a.same_t = conv_t == conv ? 1 : 0;
+    int st = ensure_pack(conv, &a.ent);
+    if (st != SCN_OK) return st;
+    st = ensure_pack(conv_t, &a.ent_t);
+    if (st != SCN_OK) return st;
+    a.rowptr = conv->g[0].d_rowptr;
+    a.rowptr_t = conv_t->g[0].d_rowptr;
+    a.x = x; a.last_nodes = last_nodes; a.y = y; a.scale = scale;
+    a.nbr = nbr; a.inc_ptr = inc_ptr; a.inc_edge = inc_edge; a.inc_sign = inc_sign;
+    for (int k = 0; k < 3 * n_layers + 1; ++k) a.W[k] = W[k];
+    char* ws = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+    a.hs = (float*)ws;
+    ws += (size_t)(n_layers - 1) * N * E * SM_C * 4;
+    a.ys = (float*)ws;
+    ws += (size_t)N * E * 16;
+    a.partial = (float*)ws;
+    const int pw = small_pw(n_layers);
+    ws += ((size_t)N * pw * 4 + 15) / 16 * 16;
+    a.loss_part = (double*)ws;
+    const SmallLds lay = small_lds(E, a.same_t != 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (lay.total > 64 * 1024)
+        SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+    hipLaunchKernelGGL(small_step_kernel, dim3(N), dim3(SM_THREADS), lay.total, s, a);
+    SCN_LAUNCH_CHECK();
+    SmallReduce r{};
+    r.n_traj = N; r.pw = pw; r.n_w = 3 * n_layers + 1; r.overwrite = overwrite ? 1 : 0;
+    int off = 0;
+    for (int k = 0; k < r.n_w; ++k) {
+        r.off[k] = off;
+        r.dW[k] = dW[k];
+        off += k < 3 ? SM_C : (k < 3 * n_layers ? SM_C * SM_C : SM_C);
+    }
+    r.off[r.n_w] = off;
+    r.partial = a.partial; r.loss_part = a.loss_part; r.loss = loss;
+    hipLaunchKernelGGL(small_reduce_kernel, dim3((pw + 15) / 16), dim3(256), 0, s, r);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@ ConvOp wraps a scn_conv_t; SconePlan / BunchPlan hold everything one model needs
 expose forward / backward over "flow slabs" ([n_slabs, rows, ns, C] fp32, see include/scone_hip.h).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -75,6 +76,7 @@ def _nbytes(*tensors):
 
 # Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
 FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
+SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"   # False: small complexes run the layer-by-layer kernels too (SconePlan.small_step returns False)
 FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
 FOLD_BUNCH = True      # False: the first two Bunch layers as ordinary layers instead of the rank-one fold (BunchPlan._fold_forward)
 
@@ -702,6 +704,8 @@ class SconePlan:
         self.nbr = to(nbr.astype(np.int32))
         self.n_nodes, self.max_deg = nbr.shape
         self._h_nbr, self._h_inc_ptr, self._h_inc_edge = nbr, np.asarray(ptr), np.asarray(edge)
+        inc_deg = np.diff(np.asarray(ptr)).astype(np.int64)             # readout items of a last node: incident edges of its neighbours
+        self.max_items = int(np.where(nbr >= 0, inc_deg[np.maximum(nbr, 0)], 0).sum(axis=1).max()) if inc_deg.size else 0
         self._ro_rows = None
         self._readout_version = getattr(bconds, "version", 0)
         self._probed = hasattr(bconds, "prepare")
@@ -879,6 +883,36 @@ class SconePlan:
     def _blocked(self):
         op = self.conv if self.conv is not None else self.op
         return op.plan_info()[0] > 0
+
+    # -- small complexes: the whole gradient step of a micro-batch in one launch (scn_small_step, csrc/scn_small.hip)
+    def small_step(self, x, last_dev, yt, scale, weights, grads, loss, overwrite=False):
+        """grads[k] += d/dW[k] of scale * sum_n <logp_n, yt_n> and loss[0] += that sum, with one workgroup per trajectory keeping
+        the activations in LDS through all layers and both directions (the reference's own sizes, TE:86-90).  False when the
+        shape is not served (hidden width other than 16, a complex too large for the LDS, ...): the caller then runs
+        forward / scn_masked_ce / backward.  overwrite: grads and loss are SET instead of accumulated into."""
+        if not SMALL_STEP or self.conv is None or self.conv.n_groups != 1 or len(weights) < 7 or (len(weights) - 1) % 3:
+            return False
+        L = (len(weights) - 1) // 3
+        S, E, ns, c_in = x.shape
+        hidden = weights[0].shape[1]
+        shapes = [(1, hidden)] * 3 + [(hidden, hidden)] * (3 * (L - 1)) + [(hidden, 1)]
+        if c_in != 1 or [tuple(w.shape) for w in weights] != shapes or tuple(yt.shape) != (S * ns, self.max_deg):
+            return False
+        lib = _lib.load()
+        if not lib.scn_small_step_supported(self.conv.handle, L, hidden, self.max_deg, self.max_items):
+            return False
+        ws = torch.empty(int(lib.scn_small_step_workspace(E, S * ns, L)), device=x.device, dtype=torch.uint8)
+        # bytes the launch has to move at least: the input flows, the saved activations written and read back, the operator
+        nb = x.numel() * 4 + 2 * (L - 1) * S * ns * E * hidden * 4 + self.conv.csr_bytes
+        with _timed("small_step L%d c%d" % (L, hidden), nb):
+            check(lib.scn_small_step(self.conv.handle, self.conv_T.handle, S, ns, L, hidden, _dev(x), _dev(last_dev, torch.int32),
+                                     _dev(yt), float(scale), _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
+                                     self.max_items, _dev(self.inc_ptr, torch.int32), _dev(self.inc_edge, torch.int32),
+                                     _dev(self.inc_sign), ptr_array([_dev(w).value for w in weights]), ACT[self.act],
+                                     ptr_array([_dev(g).value for g in grads]), ctypes.c_void_p(loss.data_ptr()),
+                                     1 if overwrite else 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                  "scn_small_step")
+        return True
 
     def promotion(self, weights):
         """Promoted hidden width of this weight list on this plan (None: runs as it is)."""

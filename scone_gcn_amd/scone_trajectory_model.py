@@ -307,12 +307,27 @@ class Scone_GCN():
             staged.append((x, last_dev, yt, activity))
         return staged
 
-    def _accumulate_staged(self, plan, staged, total):
-        """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches.  Returns that partial loss
-        as a 0-dim device tensor (no host synchronisation inside the step)."""
+    def _accumulate_staged(self, plan, staged, total, fresh=False):
+        """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches (fresh: flat_g = ..., i.e. zeroed first).
+        Returns that partial loss as a 0-dim device tensor (no host synchronisation inside the step)."""
         lib = _lib.load()
-        part = torch.zeros((1,), device=self._flat_w.device, dtype=torch.float64)
+        if fresh and len(staged) and staged[0][3] is None and type(plan) is ops.SconePlan:
+            # small complex: forward, loss and backward of a micro-batch in one launch; the first one SETS the gradient and the loss
+            part = torch.empty((1,), device=self._flat_w.device, dtype=torch.float64)
+            x, last_dev, yt, _ = staged[0]
+            if plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part, overwrite=True):
+                staged = staged[1:]
+                fresh = False
+            else:
+                part.zero_()
+        else:
+            part = torch.zeros((1,), device=self._flat_w.device, dtype=torch.float64)
+        if fresh:
+            self._flat_g.zero_()
         for x, last_dev, yt, activity in staged:
+            if activity is None and type(plan) is ops.SconePlan and \
+                    plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part):
+                continue
             logp, saved = plan.forward(x, last_dev, self.weights, activity) if activity else plan.forward(x, last_dev, self.weights)
             d_logp = torch.empty_like(logp)
             _lib.check(lib.scn_masked_ce(logp.numel(), ops._dev(logp), ops._dev(yt), -1.0 / total, ops._dev(d_logp),
@@ -357,8 +372,7 @@ class Scone_GCN():
         def body():
             if prologue is not None:
                 prologue()
-            self._flat_g.zero_()
-            return self._accumulate_staged(plan, staged, total)
+            return self._accumulate_staged(plan, staged, total, fresh=True)
         loss = body()                                    # eager: this call's result, and the warm-up of the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -375,8 +389,7 @@ class Scone_GCN():
         if len(staged) == 1 and staged[0][3] is None and self._graph_ok(plan, staged[0][0].shape[0] * ops.NS):
             loss = self._graph_accumulate(plan, staged, total)
         else:
-            self._flat_g.zero_()
-            loss = self._accumulate_staged(plan, staged, total)
+            loss = self._accumulate_staged(plan, staged, total, fresh=True)
         dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
         if apply:
             self._adam()

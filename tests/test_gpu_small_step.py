@@ -1,0 +1,162 @@
+"""GPU parity of scn_small_step (csrc/scn_small.hip): the whole gradient step of a micro-batch on a small complex in one launch --
+one workgroup per trajectory, activations resident in LDS through every layer, the readout, the cross-entropy and the backward
+(TE:137-152, STM:42-56 on the reference's own sizes, TE:86-90) -- against (a) the CPU oracle and (b) the layer-by-layer kernels
+the same trainer runs with ops.SMALL_STEP = False.  Tolerance: north_star's 1e-5 (fp32) for the oracle, 2e-6 of the largest
+gradient entry between the two GPU paths (they differ in summation order only).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import scone_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def sc1(cfg1):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.synthetic_data_gen import Complex
+    cx = Complex(n_nodes=cfg1["n_nodes"], edges=cfg1["edges"].astype(np.int64), faces=cfg1["faces"].astype(np.int64),
+                 coords=cfg1["coords"])
+    return SimplicialComplex(cx)
+
+
+def _maxdiff(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) / max(1.0, float(np.max(np.abs(b))))
+
+
+def _net(sc1, cfg1, model, layers, scale, small, graph=False, flip=False):
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    ops.SMALL_STEP = small
+    shifts, readout, flips = te.setup_from_complex(sc1, model, flip_edges=flip)
+    flows = te.apply_flips(cfg1["flows"], flips)
+    inputs = [readout, cfg1["last_nodes"], flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-2, 100, 0.0, verbose=False)
+    net.use_graph = graph
+    net.setup(te.MODEL_FUNCS[model], layers, shifts, inputs, cfg1["targets"], None, cfg1["train_mask"], model_type=model)
+    with torch.no_grad():
+        for w in net.weights:
+            w.mul_(scale)
+    return net, inputs, flips
+
+
+def _step(net, inputs, y, sel):
+    from scone_gcn_amd import ops
+    staged = net.stage(inputs, y, sel)
+    with ops.KernelTimer() as kt:                                   # (also keeps the graph path out of the way)
+        loss = float(net.grad_step_staged(inputs, staged, len(sel), apply=False))
+    return loss, net._flat_g.cpu().numpy().copy(), kt.table()
+
+
+@pytest.mark.parametrize("model,act,n_layers,n_traj", [("scone", "tanh", 3, 27), ("scone", "tanh", 2, 8), ("scone", "relu", 4, 13),
+                                                       ("ebli", "leaky_relu", 3, 21), ("scone", "tanh", 3, 1)])
+def test_small_step_matches_the_oracle_and_the_layer_by_layer_kernels(cfg1, sc1, model, act, n_layers, n_traj):
+    """|E| = 1001 (not a multiple of the 16-row tiles), hidden 16, trajectory counts that leave the last slab partly padding.  The
+    ebli case runs the same kernel on the L1 / L1^2 pair: rows of up to several dozen entries."""
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import trajectory_experiments as te
+    layers = [(3, 16)] * n_layers
+    sel = np.arange(5, 5 + n_traj)
+    scale = 8.0 if model == "scone" else 1.0
+    plan = old_act = None
+    try:
+        res = {}
+        for small in (True, False):
+            net, inputs, _ = _net(sc1, cfg1, model, layers, scale, small)
+            plan = net._plan(inputs)                                # (cached per complex: the activation is put back below)
+            old_act = plan.act if old_act is None else old_act
+            plan.act = act
+            res[small] = _step(net, inputs, cfg1["targets"], sel)
+            w = [a.cpu().numpy().astype(np.float64) for a in net.weights]
+        used = [k for k in res[True][2] if k.startswith("small_step")]
+        assert used and not any(k.startswith("small_step") for k in res[False][2]), (res[True][2].keys(), res[False][2].keys())
+        assert not any(k.startswith("conv_") for k in res[True][2])
+    finally:
+        ops.SMALL_STEP = True
+        if plan is not None:
+            plan.act = old_act
+    (la, ga, _), (lb, gb, _) = res[True], res[False]
+    gmax = np.abs(gb).max()
+    assert gmax > 1e-4
+    assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)) and np.abs(ga - gb).max() <= 2e-6 * max(gmax, 1.0)
+    # the oracle on the same trajectories
+    B1, B2 = cfg1["B1"], cfg1["B2"]
+    shifts_o = so.scone_shifts(B1, B2, None) if model == "scone" else so.ebli_shifts(B1, B2, None)
+    nb, _ = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    Bc = so.make_Bconds(B1, nb, None)
+    mask = np.ones(n_traj, int)
+    oact = act
+    ref_loss, ref_g = so.scone_loss_and_grad(w, shifts_o[0], shifts_o[1], Bc, cfg1["last_nodes"][sel], cfg1["flows"][sel],
+                                             cfg1["targets"][sel], mask, 0.0, oact)
+    assert abs(la - ref_loss) <= TOL * max(1.0, abs(ref_loss))
+    got, off = [], 0
+    for g in ref_g:
+        got.append(ga[off:off + g.size].reshape(g.shape))
+        off += g.size
+    for k, (a, b) in enumerate(zip(got, ref_g)):
+        assert _maxdiff(a, b) <= TOL, "weight %d" % k
+
+
+def test_small_step_is_bitwise_reproducible_and_flip_invariant(cfg1, sc1):
+    """Two launches on the same buffers give identical bits (fixed reduction order: waves, then trajectories); with tanh the loss
+    does not depend on the edge orientation (-flip_edges, TE:214-219, 288-296)."""
+    sel = np.arange(100, 164)
+    net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 16)] * 3, 8.0, True)
+    a = _step(net, inputs, cfg1["targets"], sel)
+    b = _step(net, inputs, cfg1["targets"], sel)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    netf, inputsf, flips = _net(sc1, cfg1, "scone", [(3, 16)] * 3, 8.0, True, flip=True)
+    assert flips is not None and (np.asarray(flips) < 0).any()
+    c = _step(netf, inputsf, cfg1["targets"], sel)
+    assert abs(a[0] - c[0]) <= 1e-6 * max(1.0, abs(a[0]))
+    assert np.abs(np.abs(a[1]) - np.abs(c[1])).max() <= 2e-6 * np.abs(a[1]).max() + 1e-7     # W_0, W_1, W_2 gradients keep their values
+
+
+def test_small_step_inside_the_replayed_graph(cfg1, sc1):
+    """The graph-replayed optimiser step (Scone_GCN._graph_accumulate) captures the one-launch step: three Adam steps replayed equal
+    three eager ones bit for bit, and the weights move."""
+    res = {}
+    for graph in (False, True):
+        net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 16)] * 3, 8.0, True, graph=graph)
+        staged = net.stage(inputs, cfg1["targets"], np.arange(40, 104))
+        w0 = net._flat_w.cpu().numpy().copy()
+        out = []
+        for _ in range(3):
+            loss = float(net.grad_step_staged(inputs, staged, 64))
+            out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
+        assert (len(net._graphs) > 0) == graph
+        assert np.abs(out[-1][2] - w0).max() > 1e-3
+        res[graph] = out
+    for (la, ga, wa), (lb, gb, wb) in zip(res[False], res[True]):
+        assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
+
+
+def test_small_step_refuses_what_it_does_not_serve(cfg1, sc1):
+    """Hidden 32, a complex beyond the LDS, a neighbourhood bound beyond the item list: scn_small_step_supported says no and the
+    entry point returns SCN_ERR_UNSUPPORTED (the trainer then runs the layer-by-layer kernels)."""
+    from scone_gcn_amd import _lib, ops
+    from scone_gcn_amd import trajectory_experiments as te
+    lib = _lib.load()
+    shifts, readout, _ = te.setup_from_complex(sc1, "scone")
+    plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+    h = plan.conv.handle
+    assert lib.scn_small_step_supported(h, 3, 16, plan.max_deg, plan.max_items) == 1
+    assert lib.scn_small_step_supported(h, 3, 32, plan.max_deg, plan.max_items) == 0
+    assert lib.scn_small_step_supported(h, 1, 16, plan.max_deg, plan.max_items) == 0
+    assert lib.scn_small_step_supported(h, 7, 16, plan.max_deg, plan.max_items) == 0
+    assert lib.scn_small_step_supported(h, 3, 16, 65, plan.max_items) == 0
+    assert lib.scn_small_step_supported(h, 3, 16, plan.max_deg, 513) == 0
+    assert lib.scn_small_step_workspace(1001, 0, 3) == 0
+    net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 32)] * 3, 8.0, True)
+    _, _, table = _step(net, inputs, cfg1["targets"], np.arange(16))
+    assert not any(k.startswith("small_step") for k in table) and any(k.startswith("conv_fwd") for k in table)

@@ -7,7 +7,7 @@ C="$ROOT/scone_gcn_amd/csrc"
 NAME=$1; EXTRA=${2:-}
 mkdir -p "$ROOT/tools/ab/obj_$NAME"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$ROOT/include -I$C -Wall -Wno-unused-result $EXTRA"
-for f in scn_conv scn_blocked scn_readout scn_dense; do
+for f in scn_conv scn_blocked scn_readout scn_dense scn_small; do
   /opt/rocm/bin/hipcc $FLAGS -c "$C/$f.hip" -o "$ROOT/tools/ab/obj_$NAME/$f.o" &
 done
 wait

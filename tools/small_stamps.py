@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Where the one-launch small step spends its time: wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries of
+small_step_kernel, from the diagnostic build (tools/build_stamps.sh -> tools/ubench/libscone_hip_stamps.so).
+usage: SCN_LIB_PATH=tools/ubench/libscone_hip_stamps.so python3 tools/small_stamps.py [n_points=400] [n_traj=100]"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scone_gcn_amd import _lib, synthetic_data_gen as g, trajectory_experiments as te, scone_trajectory_model as stm
+from scone_gcn_amd.complex import SimplicialComplex
+pts = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+cx = g.random_SC_graph(pts); sc = SimplicialComplex(cx)
+paths = g.generate_random_walks(cx, m=N, seed=1)
+flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=1)
+y = np.zeros((N, sc.max_degree, 1)); y[np.arange(N), choice, 0] = 1.0
+shifts, readout, _ = te.setup_from_complex(sc, "scone")
+inputs = [readout, last, flows]
+stm.reseed(1030)
+net = stm.Scone_GCN(1, 1e-3, N, 5e-5, verbose=False)
+net.use_graph = False
+net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+staged = net.stage(inputs, y, np.arange(N))
+lib = _lib.load()
+lib.scn_debug_small_stamps.restype = ctypes.c_int
+out = (ctypes.c_ulonglong * 16)()
+names = ["prefetch issue + x, rowptr, W1 -> LDS", "y = (x, S_lo x, S_up x)", "H1", "(-)", "layer 2", "layer 3", "", "", "",
+         "readout + CE (wave 0) | zero dz", "scatter dH, dz = dH act'(H), fence", "backward layer 3", "backward layer 2 + dW1"]
+for rep in range(3):
+    net.grad_step_staged(inputs, staged, N, apply=False)
+    torch.cuda.synchronize()
+    assert lib.scn_debug_small_stamps(out) == 0
+    st = [int(v) for v in out]
+    idx = [k for k in range(16) if st[k]]
+    print("|E| = %d, %d trajectories, run %d: total %.2f us" % (cx.n_edges, N, rep, (st[idx[-1]] - st[idx[0]]) / 100.0))
+    for a, b in zip(idx[:-1], idx[1:]):
+        print("   %6.2f us  %s" % ((st[b] - st[a]) / 100.0, names[a] if a < len(names) else ""))
