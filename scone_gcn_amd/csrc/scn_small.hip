@@ -20,16 +20,19 @@
 
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace scn {
 
-constexpr int SM_THREADS = 512, SM_WAVES = 8, SM_C = 16;      // eight waves: 256 registers per lane, room for a row's entries in flight
+constexpr int SM_THREADS = 512, SM_WAVES = 8, SM_C = 16;      // eight waves: 256 registers per lane
 constexpr int SM_MAX_LAYERS = 6;
 constexpr int SM_ITEMS = 512, SM_MAXD = 64;     // readout item list / neighbourhood width one wave handles (as scn_readout.hip)
 constexpr int SM_LAYER_W = 3 * SM_C * SM_C;     // 768 weights per layer
-constexpr int SM_CH = 12;                       // operator entries of a row requested in one go (a round trip to L2 per row otherwise)
-constexpr int SM_RO_PRE = 8;                    // readout items per neighbour slot requested at kernel start
+constexpr int SM_CH = 12;                       // operator entries of a row kept in registers (three per lane of the row's four); longer rows
+                                                // read their tail from memory in every pass
+constexpr int SM_RO_PRE = 6;                    // readout items per neighbour slot requested at kernel start
+constexpr int SM_MAXT = 9;                      // 16-row tiles per wave at most: |E| <= 16 * 8 * 9 = 1152
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -37,8 +40,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef SCN_STAMPS
 __device__ unsigned long long g_small_stamps[16];
 #define SM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[k] = wall_clock64(); } while (0)
+__device__ unsigned long long g_small_cycles[16];              // shader-clock stamps inside one forward tile (tile 0 of wave 0, layer 2)
+#define SM_CYC(k, cond) do { if (cond) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_small_cycles[k] = clock64(); } } while (0)
 #else
 #define SM_STAMP(k)
+#define SM_CYC(k, cond)
 #endif
 
 struct SmallArgs {
@@ -52,19 +59,19 @@ struct SmallArgs {
     const int32_t* nbr; const int32_t* inc_ptr; const int32_t* inc_edge; const float* inc_sign;
     const float* W[3 * SM_MAX_LAYERS + 1];
     float* hs;                                        // [n_layers - 1][N][E][16]  saved activations H_1 .. H_{L-1}
-    float* ys;                                        // [N][E][4]                 (x, S_lo x, S_up x, 0)
+    float* ys;                                        // [N][E][4]                 (x, S_lo x, S_up x, 0): written for non-symmetric shifts only
     float* partial;                                   // [N][PW]                   per-trajectory weight-gradient partials
     double* loss_part;                                // [N]
 };
 
 __host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C + (n_layers - 1) * SM_LAYER_W + SM_C; }
 
-// LDS: two activation buffers, one layer's weights, readout scratch, the row pointers, reduction scratch
+// LDS: two activation buffers, one layer's weights, readout scratch, the input flow, reduction scratch
 struct SmallLds {
     int epad;
-    size_t off_w, off_misc, off_rp, off_red, total;
+    size_t off_w, off_misc, off_x, off_red, total;
 };
-__host__ __device__ static inline SmallLds small_lds(int n_edges, bool same_t) {
+__host__ __device__ static inline SmallLds small_lds(int n_edges) {
     SmallLds L;
     L.epad = (n_edges + 15) & ~15;
     const size_t buf = (size_t)L.epad * SM_C * 4;
@@ -72,9 +79,8 @@ __host__ __device__ static inline SmallLds small_lds(int n_edges, bool same_t) {
     L.off_misc = L.off_w + SM_LAYER_W * 4;
     // misc: lgs[64] dl[64] wlast[16] d_ptr[80] it_e[512] it_s[512] it_d[512] bh[64*16] dwf[8*48]
     const size_t misc = (64 + 64 + 16 + 80 + 3 * SM_ITEMS + 64 * SM_C + SM_WAVES * 48) * 4;
-    L.off_rp = L.off_misc + misc;
-    const size_t rp = ((size_t)(n_edges + 1) * 4 + 15) / 16 * 16;
-    L.off_red = L.off_rp + (same_t ? rp : 2 * rp);
+    L.off_x = L.off_misc + misc;
+    L.off_red = L.off_x + (size_t)L.epad * 4;
     const size_t red = (size_t)SM_WAVES * SM_LAYER_W * 4;
     L.total = L.off_red + (buf >= red ? 0 : red);            // big buffers: the reduction overlays the dead input buffer
     return L;
@@ -100,47 +106,156 @@ __device__ __forceinline__ int sm_excl_scan(int v, int lane) {
     return x - v;
 }
 
-// The first SM_CH entries of a row, requested together (index 0 stands in for entries past the row's end: always readable).
-struct SmChunk { float4 e[SM_CH]; };
-__device__ __forceinline__ void sm_request(const float4* __restrict__ ent, int j0, int j1, SmChunk& c) {
+// act on a channel quad: one wave-uniform switch per quad; tanh is scn::fast_tanh's two forms evaluated side by side and selected (the
+// compiler's version of that function branches per element on whether ANY lane is small: four divergent regions per tile)
+__device__ __forceinline__ f32x4 sm_act4(int act, f32x4 z) {
+    f32x4 o;
+    if (act == SCN_ACT_TANH) {
 #pragma unroll
-    for (int u = 0; u < SM_CH; ++u) c.e[u] = ent[j0 + u < j1 ? j0 + u : 0];
-}
-// gather of one row from its requested chunk (+ the rare tail read directly): lo += val_lower * H[col][quad], up += val_upper * ..
-__device__ __forceinline__ void sm_gather(const SmChunk& c, const float4* __restrict__ ent, int j0, int j1, const float* in, int q,
-                                          f32x4& lo, f32x4& up) {
-#pragma unroll
-    for (int u = 0; u < SM_CH; ++u) {
-        if (j0 + u < j1) {
-            const f32x4 d = *(const f32x4*)(in + (size_t)__float_as_int(c.e[u].x) * SM_C + 4 * q);
-            lo += c.e[u].y * d;
-            up += c.e[u].z * d;
+        for (int j = 0; j < 4; ++j) {
+            const float x = z[j], ax = fabsf(x), x2 = x * x;
+            const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+            const float t = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
+            const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+            float big = __builtin_copysignf(r, x);
+            asm volatile("" : "+v"(big));                        // (computed unconditionally: the select below stays a v_cndmask)
+            o[j] = ax < 0.125f ? poly : big;
         }
+    } else if (act == SCN_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(z[j], 0.f);
+    } else if (act == SCN_ACT_LEAKY_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = z[j] >= 0.f ? z[j] : 0.01f * z[j];
+    } else {
+        o = z;
     }
-    for (int j = j0 + SM_CH; j < j1; j += 4) {
-        float4 e[4];
+    return o;
+}
+
+// Activation buffers hold row r's channel quad q at position q ^ ((r >> 2) & 3) of the row's 64 bytes: the sixteen lanes of a gather
+// read sixteen unrelated rows at the SAME quad, which without the rotation is four bank groups for sixteen lanes.
+__device__ __forceinline__ int sm_at(int r, int q) { return r * SM_C + 4 * (q ^ ((r >> 2) & 3)); }
+__device__ __forceinline__ int sm_at1(int r, int c) { return r * SM_C + 4 * ((c >> 2) ^ ((r >> 2) & 3)) + (c & 3); }
+
+// byte offset of row c's quad q in an activation buffer = sm_enc(c) ^ (16 * q): one v_xor per read instead of the five of sm_at
+__device__ __forceinline__ uint32_t sm_enc(int c) { return (uint32_t)(c * SM_C + 4 * ((c >> 2) & 3)) * 4u; }
+
+// The operator's rows of this lane, resident in registers for the whole kernel: tile k of the wave is rows 16 (wave + 8 k) .. + 15,
+// lane (r16, q) keeps entries u = q, q + 4, q + 8 of row 16 t + r16; the four lanes of a row hand each other their entries with
+// ds_bpermute (no memory traffic).  Every layer and, for symmetric shifts, the backward reuse them: the operator is read from memory
+// ONCE per launch instead of once per layer and tile -- those reads, a round trip to L2 each, were what the first form of this kernel
+// spent its time on (22 us per layer at |E| = 1001).
+template <int MAXT>
+struct SmOp {
+    float enc[MAXT][3], v0[MAXT][3], v1[MAXT][3];     // enc: the column as a ready byte offset into an activation buffer (sm_enc; >> 6 = the column)
+    int cnt[MAXT], cmax[MAXT];                        // entries of the row, most entries of any row of the tile (wave-uniform)
+};
+template <int MAXT>
+__device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent, int E,
+                                           int nt, int wave, int r16, int q) {
+    int j0[MAXT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = ent[j + u < j1 ? j + u : j];
+    for (int k = 0; k < MAXT; ++k) {
+        const int t = wave + SM_WAVES * k, r = 16 * t + r16;
+        const bool valid = t < nt && r < E;
+        j0[k] = valid ? rowptr[r] : 0;
+        op.cnt[k] = valid ? rowptr[r + 1] - j0[k] : 0;
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j + u < j1) {
-                const f32x4 d = *(const f32x4*)(in + (size_t)__float_as_int(e[u].x) * SM_C + 4 * q);
-                lo += e[u].y * d;
-                up += e[u].z * d;
+    for (int k = 0; k < MAXT; ++k) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int u = q + 4 * s;
+            const bool have = u < op.cnt[k];                     // entries past the row's end: column 0 with zero values, so that the
+            const float4 e = ent[have ? j0[k] + u : 0];          // gather needs no per-entry predicate (straight-line code: all LDS
+            const int c = have ? __float_as_int(e.x) : 0;        // operations of a tile issue back to back)
+            op.enc[k][s] = __int_as_float((int)sm_enc(c));
+            op.v0[k][s] = have ? e.y : 0.f;
+            op.v1[k][s] = have ? e.z : 0.f;
+        }
+        int m = op.cnt[k] < SM_CH ? op.cnt[k] : SM_CH;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
+        op.cmax[k] = __builtin_amdgcn_readfirstlane(m);
+    }
+}
+// lo += sum_u val_lower[u] * H[col_u][quad q], up likewise, over the entries of tile k's row
+template <int MAXT, int K>
+__device__ __forceinline__ void sm_gather(const SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent,
+                                          const float* in, int r, int r16, int q, f32x4& lo, f32x4& up) {
+    // Two halves of six entries, each: all eighteen exchanges, then all six reads, then the FMAs -- two LDS latencies per half instead of
+    // two per entry (a wave's tile is a latency chain: 2400 of its 4900 cycles were this gather while it went entry by entry).
+#ifndef SM_GB
+#define SM_GB 6
+#endif
+#pragma unroll
+    for (int u0 = 0; u0 < SM_CH; u0 += SM_GB) {
+        if (u0 < op.cmax[K]) {                                  // wave-uniform: every lane takes part in the exchange
+            int c[SM_GB];
+            float av[SM_GB], bv[SM_GB];
+            f32x4 d[SM_GB];
+#pragma unroll
+            for (int u = 0; u < SM_GB; ++u) {
+                const int owner = r16 + 16 * ((u0 + u) & 3), sl = (u0 + u) >> 2;
+                c[u] = __float_as_int(__shfl(op.enc[K][sl], owner, 64));
+                av[u] = __shfl(op.v0[K][sl], owner, 64);
+                bv[u] = __shfl(op.v1[K][sl], owner, 64);
+            }
+#pragma unroll
+            for (int u = 0; u < SM_GB; ++u) d[u] = *(const f32x4*)((const char*)in + ((uint32_t)c[u] ^ (uint32_t)(16 * q)));
+#pragma unroll
+            for (int u = 0; u < SM_GB; ++u) {
+                lo += av[u] * d[u];
+                up += bv[u] * d[u];
             }
         }
     }
+    if (op.cnt[K] > SM_CH) {                                    // rows longer than the register copy (the Ebli pair L1, L1^2)
+        const int j0 = rowptr[r];
+        for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
+            const float4 e = ent[j];
+            const f32x4 d = *(const f32x4*)(in + sm_at(__float_as_int(e.x), q));
+            lo += e.y * d;
+            up += e.z * d;
+        }
+    }
+}
+// (S_lo x)[row], (S_up x)[row] of tile k's row from the staged flow: each lane its own entries, the row's four lanes add up
+template <int MAXT, int K>
+__device__ __forceinline__ void sm_shift_x(const SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent,
+                                           const float* xs, int r, int q, float& lo, float& up) {
+    lo = 0.f; up = 0.f;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float xv = xs[__float_as_int(op.enc[K][s]) >> 6];
+        lo = fmaf(op.v0[K][s], xv, lo);
+        up = fmaf(op.v1[K][s], xv, up);
+    }
+    if (q == 0 && op.cnt[K] > SM_CH) {
+        const int j0 = rowptr[r];
+        for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
+            const float4 e = ent[j];
+            const float xv = xs[__float_as_int(e.x)];
+            lo = fmaf(e.y, xv, lo);
+            up = fmaf(e.z, xv, up);
+        }
+    }
+    lo += __shfl_xor(lo, 16, 64); lo += __shfl_xor(lo, 32, 64);
+    up += __shfl_xor(up, 16, 64); up += __shfl_xor(up, 32, 64);
 }
 
+template <typename F, int... Ks>
+__device__ __forceinline__ void sm_tiles(F&& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
+
+template <int MAXT>
 __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.n_edges, L = a.n_layers, act = a.act;
-    const SmallLds lay = small_lds(E, a.same_t != 0);
+    const SmallLds lay = small_lds(E);
     const int epad = lay.epad, nt = epad >> 4;
     float* const lds = (float*)smem;                            // (buffers are addressed as lds + offset: the compiler keeps LDS instructions)
     const int bufsz = epad * SM_C;                              // floats per activation buffer: A at 0, B at bufsz
-    float* bufA = lds;
-    float* bufB = lds + bufsz;
     float* Wl = (float*)(smem + lay.off_w);
     float* misc = (float*)(smem + lay.off_misc);
     float* lgs = misc;                       // [64]
@@ -152,16 +267,18 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     int* it_d = (int*)(it_s + SM_ITEMS);     // [512]
     float* bh = (float*)(it_d + SM_ITEMS);   // [64][16]
     float* dwf_red = bh + 64 * SM_C;         // [8][48]
-    int* rp = (int*)(smem + lay.off_rp);     // row pointers of the operator ...
-    int* rpt = a.same_t ? rp : rp + (((E + 1) + 3) & ~3);       // ... and of its transpose
+    float* xs = (float*)(smem + lay.off_x);  // [epad] the input flow of this trajectory
     const int n = blockIdx.x, s = n / a.ns, i = n - s * a.ns;
     const int N = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int PW = small_pw(L);
     float* my_partial = a.partial + (size_t)n * PW;
-
     SM_STAMP(0);
+#ifdef SCN_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[14] = clock64();
+#endif
+
     // ---------------- requested up front, used much later: the readout's tables of this trajectory (wave 0), its targets
     int ro_start = 0, ro_cnt = 0, ro_e[SM_RO_PRE];
     float ro_s[SM_RO_PRE], ro_y = 0.f;
@@ -182,123 +299,89 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
                 ro_s[j] = a.inc_sign[ro_start + j];
             }
     }
+    SmOp<MAXT> op;
+    sm_load_op<MAXT>(op, a.rowptr, a.ent, E, nt, wave, r16, q);
 
     // ---------------- layer 1 (one input channel): y = (x, S_lo x, S_up x), H_1 = act(y . W_1)
-    for (int e = tid; e < E; e += SM_THREADS) bufB[e] = a.x[((size_t)s * E + e) * a.ns + i];
-    for (int e = tid; e <= E; e += SM_THREADS) {
-        rp[e] = a.rowptr[e];
-        if (!a.same_t) rpt[e] = a.rowptr_t[e];
-    }
+    for (int e = tid; e < epad; e += SM_THREADS) xs[e] = e < E ? a.x[((size_t)s * E + e) * a.ns + i] : 0.f;
     if (tid < 3 * SM_C) Wl[tid] = a.W[tid / SM_C][tid % SM_C];
     if (tid < SM_C) wlast[tid] = a.W[3 * L][tid];
     __syncthreads();
     SM_STAMP(1);
-    float4* ylds = (float4*)(bufB + epad);                      // [epad] behind the staged x
     float4* ysn = (float4*)a.ys + (size_t)n * E;
-    for (int r0 = 0; r0 < epad; r0 += 2 * SM_THREADS) {         // two rows per thread and trip: both rows' entries in flight together
-        const int ra = r0 + tid, rb = r0 + SM_THREADS + tid;
-        const int ja0 = ra < E ? rp[ra] : 0, ja1 = ra < E ? rp[ra + 1] : 0;
-        const int jb0 = rb < E ? rp[rb] : 0, jb1 = rb < E ? rp[rb + 1] : 0;
-        SmChunk ca, cb;
-        sm_request(a.ent, ja0, ja1, ca);
-        sm_request(a.ent, jb0, jb1, cb);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int r = half ? rb : ra, j0 = half ? jb0 : ja0, j1 = half ? jb1 : ja1;
-            const SmChunk& c = half ? cb : ca;
-            if (r >= epad) continue;
-            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < E) {
-                float lo = 0.f, up = 0.f;
-#pragma unroll
-                for (int u = 0; u < SM_CH; ++u)
-                    if (j0 + u < j1) {
-                        const float xv = bufB[__float_as_int(c.e[u].x)];
-                        lo = fmaf(c.e[u].y, xv, lo);
-                        up = fmaf(c.e[u].z, xv, up);
-                    }
-                for (int j = j0 + SM_CH; j < j1; ++j) {
-                    const float4 en = a.ent[j];
-                    const float xv = bufB[__float_as_int(en.x)];
-                    lo = fmaf(en.y, xv, lo);
-                    up = fmaf(en.z, xv, up);
-                }
-                yv = make_float4(bufB[r], lo, up, 0.f);
-                ysn[r] = yv;
-            }
-            ylds[r] = yv;
-        }
-    }
-    __syncthreads();
-    SM_STAMP(2);
     float* hs_n = a.hs + (size_t)n * E * SM_C;                  // + layer * N * E * 16
     const size_t hs_layer = (size_t)N * E * SM_C;
-    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {
-        const int r = idx >> 2, qq = idx & 3;
-        const float4 yv = ylds[r];
-        f32x4 o;
+    {
+        float* out = lds;                                        // buffer A
+        f32x4 w0, w1, w2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 4 * qq + j;
-            const float z = yv.x * Wl[c] + yv.y * Wl[SM_C + c] + yv.z * Wl[2 * SM_C + c];
-            o[j] = r < E ? act_apply_fast(act, z) : 0.f;
-        }
-        *(f32x4*)(bufA + (size_t)r * SM_C + 4 * qq) = o;
-        if (r < E) *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * qq) = o;
+        for (int j = 0; j < 4; ++j) { w0[j] = Wl[4 * q + j]; w1[j] = Wl[SM_C + 4 * q + j]; w2[j] = Wl[2 * SM_C + 4 * q + j]; }
+        auto tile = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            int t = wave + SM_WAVES * K;
+            asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
+            if (t >= nt) return;
+            const int r = 16 * t + r16;
+            const bool valid = r < E;
+            float lo, up;
+            sm_shift_x<MAXT, K>(op, a.rowptr, a.ent, xs, r, q, lo, up);
+            const float x0 = xs[r];
+            f32x4 o;
+            o = sm_act4(act, x0 * w0 + lo * w1 + up * w2);
+            if (!valid) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(out + sm_at(r, q)) = o;
+            if (valid) {
+                *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * q) = o;
+                if (!a.same_t && q == 0) ysn[r] = make_float4(x0, lo, up, 0.f);
+            }
+        };
+        sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
     }
     __syncthreads();
-
     SM_STAMP(3);
+
     // ---------------- layers 2 .. L: out = act(H W_0 + (S_lo H) W_1 + (S_up H) W_2)
-    // a wave's tiles are wave, wave + 8, ..: while one is computed the entries of the next are on their way
-    auto row_range = [&](const int* rptr, int t, int& j0, int& j1) {
-        const int r = 16 * t + r16;
-        j0 = r < E ? rptr[r] : 0;
-        j1 = r < E ? rptr[r + 1] : 0;
-    };
     int in_o = 0, out_o = bufsz;
     for (int li = 1; li < L; ++li) {
         const float* in = lds + in_o;
         float* out = lds + out_o;
-        if (tid < SM_LAYER_W / 2) {
-            Wl[tid] = a.W[3 * li + tid / (SM_C * SM_C)][tid % (SM_C * SM_C)];
-            const int t2 = tid + SM_LAYER_W / 2;
-            Wl[t2] = a.W[3 * li + t2 / (SM_C * SM_C)][t2 % (SM_C * SM_C)];
-        }
-        SmChunk cur;
-        int j0, j1;
-        row_range(rp, wave < nt ? wave : 0, j0, j1);
-        sm_request(a.ent, j0, j1, cur);
+        for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) Wl[o] = a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)];
         __syncthreads();
         float wa[3][4];                                          // A[m = c_out = r16][k = (s, q)] = W_g[4 q + s][r16]
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u) wa[g][u] = Wl[g * 256 + (4 * q + u) * SM_C + r16];
-        for (int t = wave; t < nt; t += SM_WAVES) {
-            SmChunk nxt;
-            int n0, n1;
-            row_range(rp, t + SM_WAVES < nt ? t + SM_WAVES : t, n0, n1);     // (the last tile requests itself again: straight-line code)
-            sm_request(a.ent, n0, n1, nxt);
+        auto tile = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            int t = wave + SM_WAVES * K;
+            asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
+            if (t >= nt) return;
             const int r = 16 * t + r16;
             const bool valid = r < E;
-            f32x4 zs = {0.f, 0.f, 0.f, 0.f}, zl = zs, zu = zs;
-            if (valid) zs = *(const f32x4*)(in + (size_t)r * SM_C + 4 * q);
-            sm_gather(cur, a.ent, j0, j1, in, q, zl, zu);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            SM_CYC(0, K == 1 && li == 1);
+            f32x4 zs = *(const f32x4*)(in + sm_at(r, q)), zl = {0.f, 0.f, 0.f, 0.f}, zu = zl;     // (rows past the end hold zeros)
+            sm_gather<MAXT, K>(op, a.rowptr, a.ent, in, r, r16, q, zl, zu);
+            SM_CYC(1, K == 1 && li == 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = acc, acu = acc;   // three independent chains (a dependent MFMA waits ~40 cycles)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][u], zs[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][u], zl[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2][u], zu[u], acc, 0, 0, 0);
+                acl = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][u], zl[u], acl, 0, 0, 0);
+                acu = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2][u], zu[u], acu, 0, 0, 0);
             }
+            acc += acl + acu;
             f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = valid ? act_apply_fast(act, acc[j]) : 0.f;
-            *(f32x4*)(out + (size_t)r * SM_C + 4 * q) = o;
+            SM_CYC(2, K == 1 && li == 1);
+            o = sm_act4(act, acc);
+            if (!valid) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            SM_CYC(3, K == 1 && li == 1);
+            *(f32x4*)(out + sm_at(r, q)) = o;
             if (valid && li < L - 1) *(f32x4*)(hs_n + li * hs_layer + (size_t)r * SM_C + 4 * q) = o;
-            cur = nxt; j0 = n0; j1 = n1;
-        }
+            SM_CYC(4, K == 1 && li == 1);
+            SM_CYC(5, K == 2 && li == 1);
+        };
+        sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
         __syncthreads();
         SM_STAMP(3 + li);
         const int tmp = in_o; in_o = out_o; out_o = tmp;
@@ -338,7 +421,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
             float acc = 0.f;
             if (d < a.max_deg) {
                 const int t0 = d_ptr[d], t1 = d_ptr[d + 1];
-                for (int t = t0; t < t1; ++t) acc = fmaf(it_s[t], H[(size_t)it_e[t] * SM_C + cc], acc);
+                for (int t = t0; t < t1; ++t) acc = fmaf(it_s[t], H[sm_at1(it_e[t], cc)], acc);
                 bh[d * SM_C + cc] = acc;
             }
             float lg = d < a.max_deg ? acc * wc : 0.f;
@@ -375,21 +458,25 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
         const float wc = wlast[cc];
         const uint32_t dz_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)dz;
         for (int t = g; t < total; t += 4) {
-            const uint32_t addr = dz_addr + (uint32_t)(it_e[t] * SM_C + cc) * 4u;
+            const uint32_t addr = dz_addr + (uint32_t)sm_at1(it_e[t], cc) * 4u;
             const float v = it_s[t] * dls[it_d[t]] * wc;
             asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {     // dz_L = dH_L * act'(H_L)
+    for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {     // dz_L = dH_L * act'(H_L)  (both buffers in the same layout)
         f32x4 v = *(f32x4*)(dz + (size_t)idx * 4);
         const f32x4 h = *(const f32x4*)(H + (size_t)idx * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(act, h[j]);
         *(f32x4*)(dz + (size_t)idx * 4) = v;
     }
-    __threadfence();                                             // the saved activations (hs, ys) are read back from here on
+    // (the saved activations hs / ys are read back from here on: every store to them has been acknowledged by the L2 at a barrier since --
+    //  __syncthreads() waits for the wave's vector-memory counter -- and none of their lines has been loaded into this CU's L1 before)
+    if (!a.same_t) sm_load_op<MAXT>(op, a.rowptr_t, a.ent_t, E, nt, wave, r16, q);      // the backward gathers through the transpose
+    const float4* ent_b = a.same_t ? a.ent : a.ent_t;
+    const int32_t* rowptr_b = a.same_t ? a.rowptr : a.rowptr_t;
     __syncthreads();
     SM_STAMP(10);
 
@@ -399,32 +486,20 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     float idm[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) idm[u] = (4 * q + u == r16) ? 1.f : 0.f;
-    struct SmAux { f32x4 q; float t[4]; float4 y; };            // streamed operands of a tile: aux quad, aux with the rows along K, y
     for (int li = L - 1; li >= 1; --li) {
-        const float* aux = hs_n + (size_t)(li - 1) * hs_layer;    // H_li: the input of layer li + 1
         const float* in = lds + in_o;
         float* out = lds + out_o;
-        auto request_aux = [&](int t, SmAux& x) {
-            const int r = 16 * t + r16;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                        // A[m = c = r16][k = (u, q)] = aux[row 16 t + 4 q + u][r16]
-                const int rr = 16 * t + 4 * q + u;
-                x.t[u] = aux[(size_t)(rr < E ? rr : 0) * SM_C + r16];
+        // H_li, the input of layer li + 1, comes back into the OUTPUT buffer in one sweep (every load independent): a tile reads its rows'
+        // values there -- as the act' factor and, rows along K, as the A operand of the weight gradient -- before it writes dx over them
+        {
+            const float* aux = hs_n + (size_t)(li - 1) * hs_layer;
+            for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {
+                const int r = idx >> 2, qq = idx & 3;
+                const f32x4 v = r < E ? *(const f32x4*)(aux + (size_t)r * SM_C + 4 * qq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)(out + sm_at(r, qq)) = v;
             }
-            x.q = *(const f32x4*)(aux + (size_t)(r < E ? r : 0) * SM_C + 4 * q);
-            x.y = li == 1 ? ysn[r < E ? r : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        if (tid < SM_LAYER_W / 2) {
-            Wl[tid] = a.W[3 * li + tid / (SM_C * SM_C)][tid % (SM_C * SM_C)];
-            const int t2 = tid + SM_LAYER_W / 2;
-            Wl[t2] = a.W[3 * li + t2 / (SM_C * SM_C)][t2 % (SM_C * SM_C)];
         }
-        SmChunk cur;
-        SmAux ax;
-        int j0, j1;
-        row_range(rpt, wave < nt ? wave : 0, j0, j1);
-        sm_request(a.ent_t, j0, j1, cur);
-        request_aux(wave < nt ? wave : 0, ax);
+        for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) Wl[o] = a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)];
         __syncthreads();
         f32x4 wb[3];                                             // A[m = c = r16][k = (s, q)] = W_g[r16][4 q + s]
 #pragma unroll
@@ -437,53 +512,69 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) dwf[g][j] = 0.f;
-        for (int t = wave; t < nt; t += SM_WAVES) {
-            SmChunk nxt;
-            SmAux axn;
-            int n0, n1;
-            const int tn = t + SM_WAVES < nt ? t + SM_WAVES : t;
-            row_range(rpt, tn, n0, n1);
-            sm_request(a.ent_t, n0, n1, nxt);
-            request_aux(tn, axn);
+        auto tile = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            int t = wave + SM_WAVES * K;
+            asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
+            if (t >= nt) return;
             const int r = 16 * t + r16;
             const bool valid = r < E;
+            const f32x4 auxq = *(const f32x4*)(out + sm_at(r, q));
+            float auxT[4], g0T[4];                               // rows 16 t + 4 q + u of channel r16: aux, and dz itself (segment 0)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                auxT[u] = out[sm_at1(16 * t + 4 * q + u, r16)];
+                g0T[u] = in[sm_at1(16 * t + 4 * q + u, r16)];
+            }
             f32x4 G[3];
-            G[0] = G[1] = G[2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (valid) G[0] = *(const f32x4*)(in + (size_t)r * SM_C + 4 * q);
-            sm_gather(cur, a.ent_t, j0, j1, in, q, G[1], G[2]);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            G[0] = *(const f32x4*)(in + sm_at(r, q));
+            G[1] = G[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sm_gather<MAXT, K>(op, rowptr_b, ent_b, in, r, r16, q, G[1], G[2]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = acc, acu = acc;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[0][u], G[0][u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][u], G[1][u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[2][u], G[2][u], acc, 0, 0, 0);
+                acl = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[1][u], G[1][u], acl, 0, 0, 0);
+                acu = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[2][u], G[2][u], acu, 0, 0, 0);
             }
+            acc += acl + acu;
             f32x4 dx;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dx[j] = valid ? acc[j] * act_grad_from_output(act, ax.q[j]) : 0.f;
+            for (int j = 0; j < 4; ++j) dx[j] = valid ? acc[j] * act_grad_from_output(act, auxq[j]) : 0.f;
             if (li > 1) {
-                *(f32x4*)(out + (size_t)r * SM_C + 4 * q) = dx;
-            } else {                                             // dW_1[g][c] += y[row][g] * dx[row][c]   (dx = 0 on rows past the end)
+                asm volatile("" ::: "memory");                   // (the reads of this tile's aux rows above stay above)
+                *(f32x4*)(out + sm_at(r, q)) = dx;
+            } else {                                             // dW_1[g][c] += y[row][g] * dx[row][c]
+                float y0, y1, y2;
+                if (a.same_t) {
+                    sm_shift_x<MAXT, K>(op, rowptr_b, ent_b, xs, r, q, y1, y2);
+                    y0 = xs[r];
+                } else {
+                    const float4 yv = valid ? ysn[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    y0 = yv.x; y1 = yv.y; y2 = yv.z;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    dwf[0][j] = fmaf(ax.y.x, dx[j], dwf[0][j]);
-                    dwf[1][j] = fmaf(ax.y.y, dx[j], dwf[1][j]);
-                    dwf[2][j] = fmaf(ax.y.z, dx[j], dwf[2][j]);
+                    dwf[0][j] = fmaf(y0, dx[j], dwf[0][j]);
+                    dwf[1][j] = fmaf(y1, dx[j], dwf[1][j]);
+                    dwf[2][j] = fmaf(y2, dx[j], dwf[2][j]);
                 }
             }
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                f32x4 Gt = {0.f, 0.f, 0.f, 0.f};                 // G_g with the rows along K: lane holds rows 4 q + j of channel r16
+            for (int u = 0; u < 4; ++u) dWacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(auxT[u], g0T[u], dWacc[0], 0, 0, 0);
+            f32x4 Gt1 = {0.f, 0.f, 0.f, 0.f}, Gt2 = Gt1;         // G_g with the rows along K: lane holds rows 4 q + j of channel r16
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Gt = __builtin_amdgcn_mfma_f32_16x16x4f32(G[g][u], idm[u], Gt, 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float at = 16 * t + 4 * q + u < E ? ax.t[u] : 0.f;
-                    dWacc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, Gt[u], dWacc[g], 0, 0, 0);
-                }
+            for (int u = 0; u < 4; ++u) {
+                Gt1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G[1][u], idm[u], Gt1, 0, 0, 0);
+                Gt2 = __builtin_amdgcn_mfma_f32_16x16x4f32(G[2][u], idm[u], Gt2, 0, 0, 0);
             }
-            cur = nxt; ax = axn; j0 = n0; j1 = n1;
-        }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dWacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(auxT[u], Gt1[u], dWacc[1], 0, 0, 0);
+                dWacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(auxT[u], Gt2[u], dWacc[2], 0, 0, 0);
+            }
+        };
+        sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
         __syncthreads();                                         // every wave is done with `in`
         float* red = red_overlay ? lds + in_o : (float*)(smem + lay.off_red);
 #pragma unroll
@@ -518,6 +609,9 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
         SM_STAMP(10 + (L - li));
         const int tmp = in_o; in_o = out_o; out_o = tmp;
     }
+#ifdef SCN_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[15] = clock64();
+#endif
 }
 
 // dW[k] (+)= sum_n partial[n][...] (trajectories in a fixed order), loss (+)= sum_n loss_part[n].  One block per 16 outputs: thread
@@ -592,6 +686,9 @@ using namespace scn;
 extern "C" int scn_debug_small_stamps(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(scn::g_small_stamps), 128) == hipSuccess ? 0 : -3;
 }
+extern "C" int scn_debug_small_cycles(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(scn::g_small_cycles), 128) == hipSuccess ? 0 : -3;
+}
 #endif
 
 extern "C" {
@@ -600,7 +697,8 @@ int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, 
     if (!small_shape(conv)) return 0;
     if (n_layers < 2 || n_layers > SM_MAX_LAYERS || hidden != SM_C) return 0;
     if (max_deg <= 0 || max_deg > SM_MAXD || max_items > SM_ITEMS) return 0;
-    return small_lds(conv->n_rows, false).total <= 160 * 1024 ? 1 : 0;
+    if (conv->n_rows > 16 * SM_WAVES * SM_MAXT) return 0;
+    return small_lds(conv->n_rows).total <= 160 * 1024 ? 1 : 0;
 }
 
 size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers) {
@@ -646,11 +744,20 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     const int pw = small_pw(n_layers);
     ws += ((size_t)N * pw * 4 + 15) / 16 * 16;
     a.loss_part = (double*)ws;
-    const SmallLds lay = small_lds(E, a.same_t != 0);
+    const SmallLds lay = small_lds(E);
     hipStream_t s = (hipStream_t)stream;
-    if (lay.total > 64 * 1024)
-        SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
-    hipLaunchKernelGGL(small_step_kernel, dim3(N), dim3(SM_THREADS), lay.total, s, a);
+    const int tiles_per_wave = ((lay.epad >> 4) + SM_WAVES - 1) / SM_WAVES;
+#define SCN_LAUNCH_SMALL(T)                                                                                                   \
+    do {                                                                                                                      \
+        if (lay.total > 64 * 1024)                                                                                            \
+            SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                            (int)lay.total));                                                                 \
+        hipLaunchKernelGGL(small_step_kernel<T>, dim3(N), dim3(SM_THREADS), lay.total, s, a);                                  \
+    } while (0)
+    if (tiles_per_wave <= 3) SCN_LAUNCH_SMALL(3);
+    else if (tiles_per_wave <= 6) SCN_LAUNCH_SMALL(6);
+    else if (tiles_per_wave <= 8) SCN_LAUNCH_SMALL(8);
+    else SCN_LAUNCH_SMALL(SM_MAXT);
     SCN_LAUNCH_CHECK();
     SmallReduce r{};
     r.n_traj = N; r.pw = pw; r.n_w = 3 * n_layers + 1; r.overwrite = overwrite ? 1 : 0;

@@ -76,7 +76,12 @@ def _nbytes(*tensors):
 
 # Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
 FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
-SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"   # False: small complexes run the layer-by-layer kernels too (SconePlan.small_step returns False)
+# Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip).  SCN_SMALL_STEP=0
+# turns it off, =force lifts the size rule below.  Measured per optimiser step (graph-replayed, tools/small_step.py): |E| = 319, 160
+# trajectories 0.059 against 0.108 ms; |E| = 1001, 100 trajectories 0.125 against 0.119 ms -- one workgroup per trajectory walks eight
+# row tiles per wave there, two waves per SIMD, and that chain is as long as the five layer launches it replaces.
+SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
+SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 768     # six row tiles per wave
 FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
 FOLD_BUNCH = True      # False: the first two Bunch layers as ordinary layers instead of the rank-one fold (BunchPlan._fold_forward)
 
@@ -894,6 +899,8 @@ class SconePlan:
             return False
         L = (len(weights) - 1) // 3
         S, E, ns, c_in = x.shape
+        if E > SMALL_STEP_MAX_EDGES:
+            return False
         hidden = weights[0].shape[1]
         shapes = [(1, hidden)] * 3 + [(hidden, hidden)] * (3 * (L - 1)) + [(hidden, 1)]
         if c_in != 1 or [tuple(w.shape) for w in weights] != shapes or tuple(yt.shape) != (S * ns, self.max_deg):

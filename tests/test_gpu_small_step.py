@@ -16,6 +16,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _every_size():
+    """The trainer takes the one-launch step up to ops.SMALL_STEP_MAX_EDGES edges by default (where it is the faster path); these
+    tests run it on |E| = 1001 -- eight row tiles per wave, the largest kernel instance but one."""
+    from scone_gcn_amd import ops
+    old = ops.SMALL_STEP_MAX_EDGES
+    ops.SMALL_STEP_MAX_EDGES = 1 << 30
+    yield
+    ops.SMALL_STEP_MAX_EDGES = old
+
+
 @pytest.fixture(scope="module")
 def sc1(cfg1):
     if not torch.cuda.is_available():
@@ -160,3 +171,41 @@ def test_small_step_refuses_what_it_does_not_serve(cfg1, sc1):
     net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 32)] * 3, 8.0, True)
     _, _, table = _step(net, inputs, cfg1["targets"], np.arange(16))
     assert not any(k.startswith("small_step") for k in table) and any(k.startswith("conv_fwd") for k in table)
+
+
+@pytest.mark.parametrize("n_pts,n_traj", [(130, 37), (250, 12), (80, 5), (440, 9)])
+def test_small_step_on_other_complex_sizes_against_the_layer_by_layer_kernels(n_pts, n_traj):
+    """The kernel's instances by row tiles per wave: |E| ~ 320 (three, the drifter complex's size), ~ 620 (six), ~ 190 (two for
+    some waves, one for others) and ~ 1100 (nine: the largest complex whose two activation buffers fit the LDS)."""
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(n_pts)
+    sc = SimplicialComplex(cx)
+    paths = g.generate_random_walks(cx, m=n_traj, seed=3)
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=3)
+    y = np.zeros((n_traj, sc.max_degree, 1))
+    y[np.arange(n_traj), choice, 0] = 1.0
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    res = {}
+    try:
+        for small in (True, False):
+            ops.SMALL_STEP = small
+            stm.reseed(1030)
+            net = stm.Scone_GCN(1, 1e-2, n_traj, 0.0, verbose=False)
+            net.use_graph = False
+            net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, np.ones(n_traj, int), model_type="scone")
+            with torch.no_grad():
+                for w in net.weights:
+                    w.mul_(8.0)
+            res[small] = _step(net, inputs, y, np.arange(n_traj))
+    finally:
+        ops.SMALL_STEP = True
+    assert any(k.startswith("small_step") for k in res[True][2]), (cx.n_edges, list(res[True][2]))
+    (la, ga, _), (lb, gb, _) = res[True], res[False]
+    gmax = np.abs(gb).max()
+    assert gmax > 1e-4
+    assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)) and np.abs(ga - gb).max() <= 2e-6 * max(gmax, 1.0)

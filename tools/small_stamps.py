@@ -23,14 +23,21 @@ staged = net.stage(inputs, y, np.arange(N))
 lib = _lib.load()
 lib.scn_debug_small_stamps.restype = ctypes.c_int
 out = (ctypes.c_ulonglong * 16)()
-names = ["prefetch issue + x, rowptr, W1 -> LDS", "y = (x, S_lo x, S_up x)", "H1", "(-)", "layer 2", "layer 3", "", "", "",
-         "readout + CE (wave 0) | zero dz", "scatter dH, dz = dH act'(H), fence", "backward layer 3", "backward layer 2 + dW1"]
+names = {0: "requests issued; x, W1 -> LDS", 1: "layer 1: y = (x, S_lo x, S_up x), H1", 3: "layer 2", 4: "layer 3 (or: readout, if 2 layers)",
+         5: "readout + cross-entropy (wave 0) | zero dz", 9: "scatter dH, dz = dH act'(H), fence", 10: "backward of the last layer",
+         11: "backward of the layer before (+ dW1 if it is layer 2)", 12: "backward", 13: "backward"}
 for rep in range(3):
     net.grad_step_staged(inputs, staged, N, apply=False)
     torch.cuda.synchronize()
     assert lib.scn_debug_small_stamps(out) == 0
     st = [int(v) for v in out]
-    idx = [k for k in range(16) if st[k]]
+    idx = [k for k in range(14) if st[k]]
+    print("   s_memtime counter: %.0f ticks per us of s_memrealtime" % ((st[15] - st[14]) / ((st[idx[-1]] - st[idx[0]]) / 100.0)))
     print("|E| = %d, %d trajectories, run %d: total %.2f us" % (cx.n_edges, N, rep, (st[idx[-1]] - st[idx[0]]) / 100.0))
+    cyc = (ctypes.c_ulonglong * 16)()
+    if lib.scn_debug_small_cycles(cyc) == 0:
+        c = [int(v) for v in cyc]
+        print("   tile 1 of wave 0, layer 2 (shader cycles, every phase drained): gather %d, 12 MFMA %d, activation %d, stores %d; whole next tile %d"
+              % (c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4]))
     for a, b in zip(idx[:-1], idx[1:]):
-        print("   %6.2f us  %s" % ((st[b] - st[a]) / 100.0, names[a] if a < len(names) else ""))
+        print("   %6.2f us  %s" % ((st[b] - st[a]) / 100.0, names.get(a, "")))

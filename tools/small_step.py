@@ -9,8 +9,9 @@ from scone_gcn_amd import synthetic_data_gen as g, trajectory_experiments as te,
 from scone_gcn_amd.complex import SimplicialComplex
 eager = "eager" in sys.argv
 steps = int(next((a for a in sys.argv[1:] if a.isdigit()), 300))
-cx = g.random_SC_graph(400); sc = SimplicialComplex(cx)
-N = 100
+pts = int(os.environ.get("SCN_POINTS", "400"))                  # 400 points: |E| = 1001 (TE:86-90); 130: |E| ~ 320 (the drifter complex's size)
+cx = g.random_SC_graph(pts); sc = SimplicialComplex(cx)
+N = int(os.environ.get("SCN_TRAJ", "100"))
 paths = g.generate_random_walks(cx, m=N, seed=1)
 flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=1)
 y = np.zeros((N, sc.max_degree, 1)); y[np.arange(N), choice, 0] = 1.0
