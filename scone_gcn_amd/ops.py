@@ -76,12 +76,26 @@ def _nbytes(*tensors):
 
 # Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
 FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
-# Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip).  SCN_SMALL_STEP=0
-# turns it off, =force lifts the size rule below.  Measured per optimiser step (graph-replayed, tools/small_step.py): |E| = 319, 160
-# trajectories 0.059 against 0.108 ms; |E| = 1001, 100 trajectories 0.125 against 0.119 ms -- one workgroup per trajectory walks eight
-# row tiles per wave there, two waves per SIMD, and that chain is as long as the five layer launches it replaces.
+# Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip), one workgroup per
+# trajectory.  SCN_SMALL_STEP=0 turns it off, =force lifts the rule of small_step_pays() below.  Measured per graph-replayed optimiser
+# step, one launch against the layer-by-layer kernels, ms (tools/small_step.py, profiles/r04_small_step_ab.txt):
+#   |E| =  319:  160 trajectories 0.059 / 0.108   256: 0.061 / 0.118   512: 0.109 / 0.148   1000: 0.197 / 0.198
+#   |E| =  639:  100 trajectories 0.086 / 0.110   256: 0.091 / 0.140   512: 0.163 / 0.197
+#   |E| = 1001:  100 trajectories 0.125 / 0.119   200: 0.130 / 0.146   256: 0.134 / 0.150   512: 0.242 / 0.193   1000: 0.471 / 0.302
+# One workgroup's chain does not shorten with the batch, so the launch costs (rounds of 256 workgroups) x (chain of this |E|); the layer
+# kernels grow with the work.  At |E| = 1001 the chain is eight row tiles per wave and layer: worth it for a full round, not beyond.
 SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
-SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 768     # six row tiles per wave
+SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 768     # six row tiles per wave: beyond, full rounds only
+
+
+def small_step_pays(n_edges, n_traj, n_cus=256):
+    """The size rule for the one-launch step (see the table above); n_traj counts the padded trajectories = workgroups."""
+    rounds = -(-n_traj // n_cus)
+    if n_edges <= min(384, SMALL_STEP_MAX_EDGES):
+        return rounds <= 4
+    if n_edges <= SMALL_STEP_MAX_EDGES:
+        return rounds <= 2
+    return rounds == 1 and 2 * n_traj > n_cus
 FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
 FOLD_BUNCH = True      # False: the first two Bunch layers as ordinary layers instead of the rank-one fold (BunchPlan._fold_forward)
 
@@ -899,7 +913,7 @@ class SconePlan:
             return False
         L = (len(weights) - 1) // 3
         S, E, ns, c_in = x.shape
-        if E > SMALL_STEP_MAX_EDGES:
+        if not small_step_pays(E, S * ns):
             return False
         hidden = weights[0].shape[1]
         shapes = [(1, hidden)] * 3 + [(hidden, hidden)] * (3 * (L - 1)) + [(hidden, 1)]

@@ -12,8 +12,11 @@ steps = int(next((a for a in sys.argv[1:] if a.isdigit()), 300))
 pts = int(os.environ.get("SCN_POINTS", "400"))                  # 400 points: |E| = 1001 (TE:86-90); 130: |E| ~ 320 (the drifter complex's size)
 cx = g.random_SC_graph(pts); sc = SimplicialComplex(cx)
 N = int(os.environ.get("SCN_TRAJ", "100"))
-paths = g.generate_random_walks(cx, m=N, seed=1)
+M = min(N, 160)                                                 # walks drawn; larger batches repeat them
+paths = g.generate_random_walks(cx, m=M, seed=1)
 flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=1)
+rep = np.arange(N) % M
+flows, choice, last = flows.select(rep), np.asarray(choice)[rep], np.asarray(last)[rep]
 y = np.zeros((N, sc.max_degree, 1)); y[np.arange(N), choice, 0] = 1.0
 shifts, readout, _ = te.setup_from_complex(sc, "scone")
 inputs = [readout, last, flows]
