@@ -602,6 +602,16 @@ def main():
         configs["configs[0]"] = side_config("BASELINE configs[0]: synthetic_data_gen.py 400-point complex, 3-layer SCoNe hidden 16, batch 100 "
                                             "(the reference's own problem size; its dense-faithful CPU restatement is cpu_baseline.dense_faithful_configs0)",
                                             "scone", cx0, SimplicialComplex(cx0), 16, 100, 50, sync)
+        # the same case on the one-launch step (ops.small_step_pays leaves batch 100 at |E| = 1001 on the layer kernels: it ties them there)
+        keep = ops.SMALL_STEP_MAX_EDGES
+        ops.SMALL_STEP_MAX_EDGES = 1 << 30
+        try:
+            forced = side_config("configs[0] with scn_small_step forced (one launch per micro-batch)", "scone", cx0, SimplicialComplex(cx0),
+                                 16, 100, 50, sync)
+            configs["configs[0]"]["one_launch_step"] = {"ms_per_step": forced["ms_per_step"], "value": forced["value"],
+                                                        "unit": forced["unit"], "kernels": forced["kernels"]}
+        finally:
+            ops.SMALL_STEP_MAX_EDGES = keep
         # configs[2]: ocean drifters, full training batch (the trajectories of tests/golden/buoy.npz)
         bpath = os.path.join(ROOT, "tests", "golden", "buoy.npz")
         if os.path.exists(bpath):

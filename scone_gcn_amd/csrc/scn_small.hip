@@ -12,10 +12,13 @@
 //   lane (r = lane & 15, q = lane >> 4) of a wave owns row 16 t + r of tile t and the channel quad 4 q .. 4 q + 3: it gathers
 //   sum_j S[row][col_j] * H[col_j][quad] with 16-byte LDS reads, and that register layout IS the B operand of
 //   v_mfma_f32_16x16x4_f32 (K = channel, N = row), whose D tile comes back in the same (row, quad) layout: out^T = W^T z^T for
-//   the forward, dX^T = W G^T for the backward.  The weight gradient dW = aux^T G needs G with the rows along K: an MFMA against
-//   the identity transposes it in registers (exact: products with 1.0 and 0.0).  Everything is fp32 FMA arithmetic -- no split.
+//   the forward, dX^T = W G^T for the backward.  The weight gradient dW = aux^T G needs its operands with the rows along K: aux and
+//   segment 0 (dz itself) are read from LDS that way, the two gathered segments are transposed in registers by an MFMA against the
+//   identity (exact: products with 1.0 and 0.0).  Everything is fp32 FMA arithmetic -- no split.
+//   The operator's rows stay in REGISTERS for the whole launch (SmOp below): a lane serves the same rows in every layer.
 //
-// Served: hidden width 16, one input channel, >= 2 layers, |E| small enough for two activation buffers in 160 KB of LDS.
+// Served: hidden width 16, one input channel, 2 .. 6 layers, |E| small enough for two activation buffers in 160 KB of LDS (~1100).
+// Measured against the layer-by-layer kernels: profiles/r04_small_step_ab.txt; when the trainer takes it: ops.small_step_pays.
 #include "scn_internal.h"
 
 #include <cstring>
@@ -40,7 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef SCN_STAMPS
 __device__ unsigned long long g_small_stamps[16];
 #define SM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[k] = wall_clock64(); } while (0)
-__device__ unsigned long long g_small_cycles[16];              // shader-clock stamps inside one forward tile (tile 0 of wave 0, layer 2)
+__device__ unsigned long long g_small_cycles[16];              // shader-clock stamps inside one forward tile (tile 1 of wave 0, layer 2)
 #define SM_CYC(k, cond) do { if (cond) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
         if (threadIdx.x == 0 && blockIdx.x == 0) g_small_cycles[k] = clock64(); } } while (0)
 #else

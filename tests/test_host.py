@@ -444,3 +444,19 @@ def test_bench_roofline_is_per_kernel_family_and_cites_traffic_only_for_the_meas
     (prof / "r09_pmc_traffic.json").write_text(json.dumps(doc))
     t, src = bench.measured_traffic("main_bench", list(r["variants"]))
     assert t == 48.5e9 and "r09_pmc_traffic.json" in src
+
+
+def test_one_launch_step_is_taken_where_it_was_measured_to_pay():
+    """ops.small_step_pays: the size / batch rule of the one-launch small-complex step against the measurements it encodes
+    (profiles/r04_small_step_ab.txt, the table above ops.SMALL_STEP)."""
+    from scone_gcn_amd import ops
+    pays = ops.small_step_pays
+    assert pays(319, 160) and pays(319, 512) and pays(319, 1000) and not pays(319, 2000)
+    assert pays(639, 100) and pays(639, 512) and not pays(639, 1000)
+    assert not pays(1001, 100) and pays(1001, 200) and pays(1001, 256) and not pays(1001, 512)
+    keep = ops.SMALL_STEP_MAX_EDGES
+    try:
+        ops.SMALL_STEP_MAX_EDGES = 1 << 30               # SCN_SMALL_STEP=force
+        assert pays(1001, 100) and pays(1001, 512)
+    finally:
+        ops.SMALL_STEP_MAX_EDGES = keep

@@ -24,7 +24,7 @@ lib = _lib.load()
 lib.scn_debug_small_stamps.restype = ctypes.c_int
 out = (ctypes.c_ulonglong * 16)()
 names = {0: "requests issued; x, W1 -> LDS", 1: "layer 1: y = (x, S_lo x, S_up x), H1", 3: "layer 2", 4: "layer 3 (or: readout, if 2 layers)",
-         5: "readout + cross-entropy (wave 0) | zero dz", 9: "scatter dH, dz = dH act'(H), fence", 10: "backward of the last layer",
+         5: "readout + cross-entropy (wave 0) | zero dz", 9: "scatter dH, dz = dH act'(H)", 10: "backward of the last layer",
          11: "backward of the layer before (+ dW1 if it is layer 2)", 12: "backward", 13: "backward"}
 for rep in range(3):
     net.grad_step_staged(inputs, staged, N, apply=False)
