@@ -291,7 +291,14 @@ class Scone_GCN():
         if P:
             widths = [w if w == 1 else P for w in widths]
         rows = sum(plan.sizes) if self.model_type == 'bunch' else plan.n_edges
-        mb = ops.micro_batch_size(rows, widths, len(idx), device=device)
+        budget = None
+        if self.model_type == 'bunch' and ops.FOLD_BUNCH and len(widths) > 3 and widths[1] == widths[2] == 32:
+            # the first hidden layer is never materialised (rank-one fold) and levels the loss cannot see are not
+            # computed: measured 0.93 GB per trajectory at |E| = 1M where the generic estimate says 1.3 -- 128 trajectories per launch
+            # (119 GB at peak) instead of 64, +3.4 % on configs[4] (tools/mb_sweep.py)
+            widths = [widths[0]] + widths[2:]
+            budget = 0.5 * torch.cuda.mem_get_info(device)[1]
+        mb = ops.micro_batch_size(rows, widths, len(idx), budget_bytes=budget, device=device)
         staged = []
         for c0 in range(0, len(idx), mb):
             sel = idx[c0:c0 + mb]

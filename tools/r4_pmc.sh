@@ -17,12 +17,12 @@ step pmc_main_bench 400 bash tools/pmc_run.sh $OUT/pmc_main_bench fetch,write,tc
 step pmc_main 400 bash tools/pmc_run.sh $OUT/pmc_main fetch,write,tcc tools/prof_kernels.py --which spmm,fwd,bwd,fwd1,bwdf --reps 2
 step pmc_cfg1 300 bash tools/pmc_run.sh $OUT/pmc_cfg1 fetch,write,tcc tools/prof_kernels.py --edges 50000 --hidden 16 --slabs 256 --which fwd,bwd,fwd1,bwdf --reps 2
 step pmc_ebli 400 bash tools/pmc_run.sh $OUT/pmc_ebli fetch,write,tcc tools/prof_ebli.py --reps 2
-step pmc_bunch 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc tools/prof_bunch.py --reps 2
+step pmc_bunch 400 bash tools/pmc_run.sh $OUT/pmc_bunch fetch,write,tcc tools/prof_bunch.py --reps 2 --slabs 32
 python3 tools/pmc_merge.py $OUT/pmc_traffic.json \
   "main_bench=$OUT/pmc_main_bench/pmc.json:|E|=996634, hidden 32, the benchmark's own trajectories: 2 optimiser steps of 512 trajectories = 8 micro-batches of 128 (tools/skip_step.py dense 2 512)" \
   "main=$OUT/pmc_main/pmc.json:|E|=996634, hidden 32, 32 slabs = 128 trajectories of dense random data (tools/prof_kernels.py --which spmm,fwd,bwd,fwd1,bwdf)" \
   "configs[1]=$OUT/pmc_cfg1/pmc.json:|E|=49616, hidden 16, 256 slabs = 1024 trajectories of dense random data (tools/prof_kernels.py --edges 50000 --hidden 16 --slabs 256)" \
   "ebli=$OUT/pmc_ebli/pmc.json:|E|=996634, hidden 32, 32 slabs of dense random data (tools/prof_ebli.py)" \
-  "bunch=$OUT/pmc_bunch/pmc.json:|E|=996634, hidden 32, 16 slabs = 64 trajectories of dense random data, the model's third-layer launches (tools/prof_bunch.py)" \
+  "bunch=$OUT/pmc_bunch/pmc.json:|E|=996634, hidden 32, 32 slabs = 128 trajectories of dense random data, the model's third-layer launches (tools/prof_bunch.py --slabs 32)" \
   > $OUT/merge.log 2>&1
 echo "merge rc=$?" | tee -a $OUT/status.txt
