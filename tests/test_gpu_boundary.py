@@ -367,3 +367,53 @@ def test_bench_lines_of_one_and_two_ranks_agree_on_loss_and_weights():
     va, vb = a["validation"], b["validation"]
     assert abs(va["weights_sum"] - vb["weights_sum"]) <= 1e-6 * max(1.0, abs(va["weights_sum"]))
     assert abs(va["weights_l2"] - vb["weights_l2"]) <= 1e-6 * va["weights_l2"]
+
+
+def test_evaluation_cache_follows_every_way_the_weights_can_change(cfg1):
+    """Scone_GCN.loss / accuracy on a small data set read ONE forward of the whole set per weight version (the epoch-end passes of
+    train(), STM:328-337).  The cached log-probabilities must follow an optimiser step (a raw-pointer write), an in-place torch
+    operation on a weight view, load_weights, other masks and other input objects -- against the uncached evaluation each time."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.synthetic_data_gen import Complex
+    cx = Complex(n_nodes=cfg1["n_nodes"], edges=cfg1["edges"].astype(np.int64), faces=cfg1["faces"].astype(np.int64), coords=cfg1["coords"])
+    sc = SimplicialComplex(cx)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    N = 300
+    inputs = [readout, cfg1["last_nodes"][:N], cfg1["flows"][:N]]
+    y, n_nbrs = cfg1["targets"][:N], sc.n_nbrs(cfg1["last_nodes"][:N])
+    train = cfg1["train_mask"][:N]
+    test = 1 - train
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-2, 50, 5e-5, verbose=False)
+    net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, train, model_type="scone")
+
+    def both():
+        out = []
+        for cached in (True, False):
+            net.use_eval_cache = cached
+            out.append((net.loss(net.weights, inputs, y, train), net.accuracy(shifts, inputs, y, train, n_nbrs),
+                        net.loss(net.weights, inputs, y, test), net.accuracy(shifts, inputs, y, test, n_nbrs)))
+        net.use_eval_cache = True
+        assert out[0] == out[1], out
+        return out[0]
+    seen = [both()]
+    bm = np.zeros(N, int)
+    bm[:50] = 1
+    net.grad_step(inputs, y, np.logical_and(bm, train))                    # Adam: a raw-pointer write
+    seen.append(both())
+    with torch.no_grad():
+        net.weights[3].mul_(1.5)                                            # an in-place operation on a view of the flat buffer
+    seen.append(both())
+    assert len({s[0] for s in seen}) == 3                                   # the loss moved each time: nothing stale was served
+    assert net._eval is not None and net._eval["n"] == N
+    other = [readout, cfg1["last_nodes"][N:2 * N], cfg1["flows"][N:2 * N]]  # other input objects: a new staging, a new forward
+    net.use_eval_cache = True
+    a = net.loss(net.weights, other, cfg1["targets"][N:2 * N], np.ones(N, int))
+    net.use_eval_cache = False
+    b = net.loss(net.weights, other, cfg1["targets"][N:2 * N], np.ones(N, int))
+    assert a == b
