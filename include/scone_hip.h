@@ -208,6 +208,16 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
                       const int32_t* sample_of, const int32_t* edge_idx, const float* val,
                       float* x, void* stream);
 
+/* HOST-ONLY helper of the launch-amortised step (nothing is launched, no device pointer is touched): assemble one batch for
+ * scn_scatter_flows + the readout / loss in the caller's staging words (typically pinned memory, copied to the device in one transfer):
+ *   out = [sample_of: e_cap][edge: e_cap][val: e_cap floats][last_nodes: n_cap][y / total: n_cap x d floats], unused words 0
+ * from the ragged flows (ptr [N + 1], edge / val per entry; path_to_flow, SDG:327-344), last_nodes [N] and targets y [N][d] of the
+ * whole data set and the batch's trajectory indices traj [m].  Returns the number of flow entries written, SCN_ERR_UNSUPPORTED when
+ * the batch does not fit (m > n_cap or more than e_cap entries), or another negative status. */
+int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, const int64_t* ptr, const int32_t* edge, const float* val,
+                             const int32_t* last_nodes, const float* y, int32_t d, double total, int32_t e_cap,
+                             int32_t n_cap, int32_t* out);
+
 /* Layers whose second shift is the square of the first (Ebli / SNN: S_lower = L1, S_upper = L1^2, TE:155-167, 251-253) on
  * complexes where the rows of the square no longer fit the LDS-blocked plan.  `conv` holds S alone (identity + ONE value
  * array); the caller forms y = S x (forward) or g1 = S^T dz (backward) with scn_spmm_dual and these calls do the rest:

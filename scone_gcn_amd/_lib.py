@@ -64,6 +64,8 @@ SIGNATURES = {
                                                 c_void_p, c_void_p]),
     "scn_node_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
                                                  c_void_p, c_i32, c_void_p, c_void_p]),
+    "scn_host_stage_batch": (c_i64, [c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_double, c_i32,
+                                     c_i32, c_void_p]),
     "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
     "scn_conv_dw_first_workspace": (c_size_t, [c_void_p, c_i32, c_i32, c_i32]),

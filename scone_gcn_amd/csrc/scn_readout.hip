@@ -655,6 +655,39 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
     return SCN_OK;
 }
 
+// Host-only: one batch of ragged flows, last nodes and targets into the caller's (pinned) staging words -- what a graph-replayed step
+// copies to the device in ONE transfer.  Plain loops: the same assembly in NumPy was 85 us of a 155 us optimiser step on the
+// reference's own configuration (a dozen array calls on ~1000 elements each).
+int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, const int64_t* ptr, const int32_t* edge, const float* val,
+                             const int32_t* last_nodes, const float* y, int32_t d, double total, int32_t e_cap,
+                             int32_t n_cap, int32_t* out) {
+    if (m < 0 || d <= 0 || e_cap <= 0 || n_cap <= 0 || !(total > 0.0)) return SCN_ERR_BAD_SHAPE;
+    if (!out || (m > 0 && (!traj || !ptr || !edge || !val || !last_nodes || !y))) return SCN_ERR_BAD_ARG;
+    if (m > n_cap) return SCN_ERR_UNSUPPORTED;
+    int64_t k = 0;
+    for (int32_t j = 0; j < m; ++j) k += ptr[traj[j] + 1] - ptr[traj[j]];
+    if (k > e_cap) return SCN_ERR_UNSUPPORTED;
+    const size_t n_words = (size_t)3 * e_cap + n_cap + (size_t)n_cap * d;
+    std::memset(out, 0, n_words * sizeof(int32_t));
+    int32_t* sample = out;
+    int32_t* eidx = out + e_cap;
+    float* v = (float*)(out + 2 * (size_t)e_cap);
+    int32_t* last = out + 3 * (size_t)e_cap;
+    float* yo = (float*)(out + 3 * (size_t)e_cap + n_cap);
+    int64_t o = 0;
+    for (int32_t j = 0; j < m; ++j) {
+        const int32_t n = traj[j];
+        for (int64_t t = ptr[n]; t < ptr[n + 1]; ++t, ++o) {
+            sample[o] = j;
+            eidx[o] = edge[t];
+            v[o] = val[t];
+        }
+        last[j] = last_nodes[n];
+        for (int32_t c = 0; c < d; ++c) yo[(size_t)j * d + c] = (float)((double)y[(size_t)n * d + c] / total);
+    }
+    return k;
+}
+
 int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, void* stream) {
     if (n <= 0) return SCN_ERR_BAD_SHAPE;
     if (!logp || !y || !d_logp || !loss) return SCN_ERR_BAD_ARG;

@@ -75,6 +75,11 @@ class _StaticStage:
         self.y_d = self.dev[3 * e + n:].view(torch.float32).view(n, D)
         self.x = torch.zeros((self.S, E, ops.NS, 1), device=device, dtype=torch.float32)
         self.staged = (self.x, self.last_d, self.y_d, None)
+        # the data set as the native assembler takes it (scn_host_stage_batch): entries with their device row index, per trajectory
+        self._ptr = np.ascontiguousarray(X.ptr, np.int64)
+        self._edge = np.ascontiguousarray(self.perm[X.idx], np.int32)
+        self._val = np.ascontiguousarray(X.val, np.float32)
+        self._last_src = self._last = self._y_src = self._y = None
 
     def load(self, idx, last_nodes, y, total):
         X, e, n = self.X, self.e_cap, self.n_cap
@@ -89,17 +94,16 @@ class _StaticStage:
         self.turn ^= 1
         if self.done[t] is not None:
             self.done[t].synchronize()                                   # the copy that last read this host buffer (two steps ago)
-        h = self.host[t].numpy()
-        h[:] = 0
-        if k:
-            off = np.concatenate([[0], np.cumsum(lens)[:-1]])
-            take = np.repeat(starts - off, lens) + np.arange(k)
-            h[0:k] = np.repeat(np.arange(m, dtype=np.int32), lens)
-            h[e:e + k] = self.perm[X.idx[take]]
-            h[2 * e:2 * e + k] = X.val[take].astype(np.float32).view(np.int32)
-        h[3 * e:3 * e + m] = np.asarray(last_nodes)[idx]
-        yv = (np.asarray(y)[idx].reshape(m, -1) / float(total)).astype(np.float32)
-        h[3 * e + n:3 * e + n + m * self.D] = yv.view(np.int32).ravel()
+        if self._last_src is not last_nodes:                             # the data set's last nodes / targets, converted once per object
+            self._last_src, self._last = last_nodes, np.ascontiguousarray(np.asarray(last_nodes), np.int32)
+        if self._y_src is not y:
+            self._y_src, self._y = y, np.ascontiguousarray(np.asarray(y, np.float32).reshape(len(y), -1))
+        traj = np.ascontiguousarray(idx, np.int32)
+        got = _lib.load().scn_host_stage_batch(m, traj.ctypes.data, self._ptr.ctypes.data, self._edge.ctypes.data,
+                                               self._val.ctypes.data, self._last.ctypes.data, self._y.ctypes.data, self.D,
+                                               float(total), e, n, self.host[t].data_ptr())
+        if got != k:
+            raise RuntimeError("scn_host_stage_batch: %d (expected %d flow entries)" % (got, k))
         self.dev.copy_(self.host[t], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -223,6 +227,8 @@ class Scone_GCN():
 
     # ------------------------------------------------------------------ loss / metrics
     def _ridge(self, weights):
+        if weights is self.weights and self._flat_w is not None:          # one reduction and one host synchronisation, not one per matrix
+            return self.weight_decay * float((self._flat_w.double() ** 2).sum())
         return self.weight_decay * sum(float((w.double() ** 2).sum()) for w in weights)   # STM:54-56
 
     # On the reference's own sizes an epoch of train() is 8 optimiser steps (~0.2 ms each) and four evaluation passes -- train loss, train

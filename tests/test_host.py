@@ -460,3 +460,41 @@ def test_one_launch_step_is_taken_where_it_was_measured_to_pay():
         assert pays(1001, 100) and pays(1001, 512)
     finally:
         ops.SMALL_STEP_MAX_EDGES = keep
+
+
+def test_native_batch_assembler_fills_the_staging_words_like_the_numpy_reference():
+    """scn_host_stage_batch (host-only entry point of the library) against a NumPy assembly of the same staging words: ragged flows
+    of a batch as (trajectory slot, device edge row, value) triples, last nodes, targets / total, zeros elsewhere; a batch that does
+    not fit is refused."""
+    import ctypes
+    from scone_gcn_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    N, D, E = 40, 7, 90
+    lens = rs.randint(0, 9, size=N)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    edge = rs.randint(0, E, size=ptr[-1]).astype(np.int32)
+    val = rs.randn(ptr[-1]).astype(np.float32)
+    last = rs.randint(0, 30, size=N).astype(np.int32)
+    y = rs.rand(N, D).astype(np.float32)
+    e_cap, n_cap, total = 64, 12, 9.0
+    n_words = 3 * e_cap + n_cap + n_cap * D
+    for traj in ([3, 17, 4, 4, 39], [], [0]):
+        traj = np.asarray(traj, np.int32)
+        out = np.full(n_words, -1, np.int32)
+        got = lib.scn_host_stage_batch(len(traj), traj.ctypes.data, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data,
+                                       y.ctypes.data, D, total, e_cap, n_cap, out.ctypes.data)
+        ref = np.zeros(n_words, np.int32)
+        k = 0
+        for j, n in enumerate(traj):
+            for t in range(ptr[n], ptr[n + 1]):
+                ref[k], ref[e_cap + k] = j, edge[t]
+                ref[2 * e_cap + k] = val[t:t + 1].view(np.int32)[0]
+                k += 1
+            ref[3 * e_cap + j] = last[n]
+            ref[3 * e_cap + n_cap + j * D:3 * e_cap + n_cap + (j + 1) * D] = (y[n].astype(np.float64) / total).astype(np.float32).view(np.int32)
+        assert got == k and np.array_equal(out, ref)
+    big = np.arange(N, dtype=np.int32)
+    out = np.zeros(n_words, np.int32)
+    assert lib.scn_host_stage_batch(N, big.ctypes.data, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data, y.ctypes.data,
+                                    D, total, e_cap, n_cap, out.ctypes.data) == _lib.SCN_ERR_UNSUPPORTED
