@@ -72,7 +72,8 @@ __host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C +
 // LDS: two activation buffers, one layer's weights, readout scratch, the input flow, reduction scratch
 struct SmallLds {
     int epad;
-    size_t off_w, off_misc, off_x, off_red, total;
+    bool y_lds;                                       // (S_lo x, S_up x) of every row stay in LDS for the first layer's weight gradient
+    size_t off_w, off_misc, off_x, off_red, off_y, total;
 };
 __host__ __device__ static inline SmallLds small_lds(int n_edges) {
     SmallLds L;
@@ -86,6 +87,9 @@ __host__ __device__ static inline SmallLds small_lds(int n_edges) {
     L.off_red = L.off_x + (size_t)L.epad * 4;
     const size_t red = (size_t)SM_WAVES * SM_LAYER_W * 4;
     L.total = L.off_red + (buf >= red ? 0 : red);            // big buffers: the reduction overlays the dead input buffer
+    L.off_y = L.total;
+    L.y_lds = L.total + (size_t)L.epad * 8 <= 160 * 1024;    // (the largest complexes recompute them from the flow instead)
+    if (L.y_lds) L.total += (size_t)L.epad * 8;
     return L;
 }
 
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     float* bh = (float*)(it_d + SM_ITEMS);   // [64][16]
     float* dwf_red = bh + 64 * SM_C;         // [8][48]
     float* xs = (float*)(smem + lay.off_x);  // [epad] the input flow of this trajectory
+    float2* ysl = (float2*)(smem + lay.off_y);  // [epad] (S_lo x, S_up x), when there is room (lay.y_lds)
     const int n = blockIdx.x, s = n / a.ns, i = n - s * a.ns;
     const int N = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,25 +287,17 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[14] = clock64();
 #endif
 
-    // ---------------- requested up front, used much later: the readout's tables of this trajectory (wave 0), its targets
-    int ro_start = 0, ro_cnt = 0, ro_e[SM_RO_PRE];
+    // ---------------- the readout's tables of this trajectory (wave 0) are a chain of four dependent loads: last node -> neighbour ->
+    // incidence range -> incident edges.  One link per phase, each issued where the previous one has long landed, so that no barrier of
+    // the forward waits for a round trip of the chain (done in one go at the top it held the first barrier back by ~5 us).
+    int ro_v = -1, ro_start = 0, ro_cnt = 0, ro_e[SM_RO_PRE];
     float ro_s[SM_RO_PRE], ro_y = 0.f;
 #pragma unroll
     for (int j = 0; j < SM_RO_PRE; ++j) { ro_e[j] = 0; ro_s[j] = 0.f; }
+    int ro_vlast = 0;
     if (wave == 0 && lane < a.max_deg) {
-        const int vlast = a.last_nodes[n];
-        const int v = a.nbr[(size_t)vlast * a.max_deg + lane];
+        ro_vlast = a.last_nodes[n];
         ro_y = a.y[(size_t)n * a.max_deg + lane];
-        if (v >= 0) {
-            ro_start = a.inc_ptr[v];
-            ro_cnt = a.inc_ptr[v + 1] - ro_start;
-        }
-#pragma unroll
-        for (int j = 0; j < SM_RO_PRE; ++j)
-            if (j < ro_cnt) {
-                ro_e[j] = a.inc_edge[ro_start + j];
-                ro_s[j] = a.inc_sign[ro_start + j];
-            }
     }
     SmOp<MAXT> op;
     sm_load_op<MAXT>(op, a.rowptr, a.ent, E, nt, wave, r16, q);
@@ -310,6 +307,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     if (tid < 3 * SM_C) Wl[tid] = a.W[tid / SM_C][tid % SM_C];
     if (tid < SM_C) wlast[tid] = a.W[3 * L][tid];
     __syncthreads();
+    if (wave == 0 && lane < a.max_deg) ro_v = a.nbr[(size_t)ro_vlast * a.max_deg + lane];
     SM_STAMP(1);
     float4* ysn = (float4*)a.ys + (size_t)n * E;
     float* hs_n = a.hs + (size_t)n * E * SM_C;                  // + layer * N * E * 16
@@ -333,14 +331,19 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
             o = sm_act4(act, x0 * w0 + lo * w1 + up * w2);
             if (!valid) o = f32x4{0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(out + sm_at(r, q)) = o;
+            if (lay.y_lds && q == 0) ysl[r] = make_float2(lo, up);
             if (valid) {
                 *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * q) = o;
-                if (!a.same_t && q == 0) ysn[r] = make_float4(x0, lo, up, 0.f);
+                if (!lay.y_lds && !a.same_t && q == 0) ysn[r] = make_float4(x0, lo, up, 0.f);
             }
         };
         sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
     }
     __syncthreads();
+    if (wave == 0 && ro_v >= 0) {
+        ro_start = a.inc_ptr[ro_v];
+        ro_cnt = a.inc_ptr[ro_v + 1] - ro_start;
+    }
     SM_STAMP(3);
 
     // ---------------- layers 2 .. L: out = act(H W_0 + (S_lo H) W_1 + (S_up H) W_2)
@@ -386,6 +389,14 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
         };
         sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
         __syncthreads();
+        if (li == 1 && wave == 0) {
+#pragma unroll
+            for (int j = 0; j < SM_RO_PRE; ++j)
+                if (j < ro_cnt) {
+                    ro_e[j] = a.inc_edge[ro_start + j];
+                    ro_s[j] = a.inc_sign[ro_start + j];
+                }
+        }
         SM_STAMP(3 + li);
         const int tmp = in_o; in_o = out_o; out_o = tmp;
     }
@@ -549,7 +560,10 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
                 *(f32x4*)(out + sm_at(r, q)) = dx;
             } else {                                             // dW_1[g][c] += y[row][g] * dx[row][c]
                 float y0, y1, y2;
-                if (a.same_t) {
+                if (lay.y_lds) {
+                    const float2 lu = ysl[r];
+                    y0 = xs[r]; y1 = lu.x; y2 = lu.y;
+                } else if (a.same_t) {
                     sm_shift_x<MAXT, K>(op, rowptr_b, ent_b, xs, r, q, y1, y2);
                     y0 = xs[r];
                 } else {
