@@ -417,3 +417,37 @@ def test_evaluation_cache_follows_every_way_the_weights_can_change(cfg1):
     net.use_eval_cache = False
     b = net.loss(net.weights, other, cfg1["targets"][N:2 * N], np.ones(N, int))
     assert a == b
+
+
+def test_evaluation_cache_with_the_bunch_model_and_a_probed_readout_closure(cfg1):
+    """The same cache under the other plan types: a Bunch model (BunchPlan, node readout) and a scone model whose readout operand is a
+    plain Bcond_func closure probed on demand (ProbedBconds: the tables grow with the last nodes seen) -- cached == uncached."""
+    _need_gpu()
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    from scone_gcn_amd.synthetic_data_gen import Complex
+    cx = Complex(n_nodes=cfg1["n_nodes"], edges=cfg1["edges"].astype(np.int64), faces=cfg1["faces"].astype(np.int64), coords=cfg1["coords"])
+    sc = SimplicialComplex(cx)
+    N = 120
+    y, last, flows = cfg1["targets"][:N], cfg1["last_nodes"][:N], cfg1["flows"][:N]
+    n_nbrs = sc.n_nbrs(last)
+    mask = (np.arange(N) % 3 != 0).astype(int)
+    nb, D = so.neighborhoods(cfg1["edges"], cfg1["n_nodes"])
+    closure = so.make_Bconds(cfg1["B1"], nb, None)
+    cases = []
+    shifts_b, readout_b, _ = te.setup_from_complex(sc, "bunch")
+    cases.append(("bunch", te.bunch_func, [(7, 16)] * 2, shifts_b, readout_b))
+    shifts_s, _, _ = te.setup_from_complex(sc, "scone")
+    cases.append(("scone", te.scone_func, [(3, 16)] * 2, shifts_s, closure))
+    for model, fn, layers, shifts, readout in cases:
+        inputs = [readout, last, flows]
+        stm.reseed(1030)
+        net = stm.Scone_GCN(1, 1e-2, 40, 0.0, verbose=False)
+        net.setup(fn, layers, shifts, inputs, y, None, mask, model_type=model)
+        got = []
+        for cached in (True, False, True):
+            net.use_eval_cache = cached
+            got.append((net.loss(net.weights, inputs, y, mask), net.accuracy(shifts, inputs, y, mask, n_nbrs),
+                        net.loss(net.weights, inputs, y, 1 - mask)))
+        assert got[0] == got[1] == got[2], (model, got)

@@ -209,3 +209,51 @@ def test_small_step_on_other_complex_sizes_against_the_layer_by_layer_kernels(n_
     gmax = np.abs(gb).max()
     assert gmax > 1e-4
     assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)) and np.abs(ga - gb).max() <= 2e-6 * max(gmax, 1.0)
+
+
+def test_host_batches_through_the_replayed_graph_take_the_one_launch_step():
+    """Scone_GCN.grad_step on a drifter-sized complex (|E| = 319: the default rule applies): host batches of four different sizes go
+    through the fixed-address staging buffers (filled by scn_host_stage_batch), the captured graph holds scn_scatter_flows +
+    scn_small_step, and four Adam steps end at the weights of the layer-by-layer kernels (summation order apart)."""
+    from scone_gcn_amd import ops
+    from scone_gcn_amd import scone_trajectory_model as stm
+    from scone_gcn_amd import synthetic_data_gen as g
+    from scone_gcn_amd import trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    keep = ops.SMALL_STEP_MAX_EDGES
+    ops.SMALL_STEP_MAX_EDGES = 768                                  # the shipped rule, whatever the fixture set
+    cx = g.random_SC_graph(130)
+    sc = SimplicialComplex(cx)
+    N = 160
+    paths = g.generate_random_walks(cx, m=N, seed=5)
+    flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=5)
+    y = np.zeros((N, sc.max_degree, 1))
+    y[np.arange(N), choice, 0] = 1.0
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    inputs = [readout, last, flows]
+    res = {}
+    try:
+        for small in (True, False):
+            ops.SMALL_STEP = small
+            stm.reseed(1030)
+            net = stm.Scone_GCN(1, 1e-2, 64, 5e-5, verbose=False)
+            net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
+            with torch.no_grad():
+                for w in net.weights:
+                    w.mul_(8.0)
+            rs = np.random.RandomState(2)
+            out = []
+            for step in range(4):
+                m = np.zeros(N, int)
+                m[rs.choice(N, 64 - 9 * step, replace=False)] = 1
+                net._step = step
+                out.append((float(net.grad_step(inputs, y, m)), net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy()))
+            assert len(net._graphs) > 0
+            res[small] = out
+    finally:
+        ops.SMALL_STEP = True
+        ops.SMALL_STEP_MAX_EDGES = keep
+    for (la, ga, wa), (lb, gb, wb) in zip(res[True], res[False]):
+        gmax = np.abs(gb).max()
+        assert gmax > 1e-5
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)) and np.abs(ga - gb).max() <= 2e-6 * max(gmax, 1.0) and np.abs(wa - wb).max() <= 5e-6
