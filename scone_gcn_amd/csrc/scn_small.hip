@@ -28,7 +28,9 @@
 
 namespace scn {
 
-constexpr int SM_THREADS = 512, SM_WAVES = 8, SM_C = 16;      // eight waves: 256 registers per lane
+constexpr int SM_C = 16;
+constexpr int SM_WAVES_MAX = 12;                // waves per workgroup: 8 (256 registers per lane: up to nine row tiles per wave resident) or, for
+                                                // complexes of at most 24 tiles, 12 (170 registers, one or two tiles per wave, three waves per SIMD)
 constexpr int SM_MAX_LAYERS = 6;
 constexpr int SM_ITEMS = 512, SM_MAXD = 64;     // readout item list / neighbourhood width one wave handles (as scn_readout.hip)
 constexpr int SM_LAYER_W = 3 * SM_C * SM_C;     // 768 weights per layer
@@ -75,17 +77,19 @@ struct SmallLds {
     bool y_lds;                                       // (S_lo x, S_up x) of every row stay in LDS for the first layer's weight gradient
     size_t off_w, off_misc, off_x, off_red, off_y, total;
 };
+__host__ __device__ static inline int small_waves(int n_edges) { return ((n_edges + 15) >> 4) <= 24 ? 12 : 8; }
 __host__ __device__ static inline SmallLds small_lds(int n_edges) {
+    const int waves = small_waves(n_edges);
     SmallLds L;
     L.epad = (n_edges + 15) & ~15;
     const size_t buf = (size_t)L.epad * SM_C * 4;
     L.off_w = 2 * buf;
     L.off_misc = L.off_w + SM_LAYER_W * 4;
-    // misc: lgs[64] dl[64] wlast[16] d_ptr[80] it_e[512] it_s[512] it_d[512] bh[64*16] dwf[8*48]
-    const size_t misc = (64 + 64 + 16 + 80 + 3 * SM_ITEMS + 64 * SM_C + SM_WAVES * 48) * 4;
+    // misc: lgs[64] dl[64] wlast[16] d_ptr[80] it_e[512] it_s[512] it_d[512] bh[64*16] dwf[waves*48]
+    const size_t misc = (64 + 64 + 16 + 80 + 3 * SM_ITEMS + 64 * SM_C + waves * 48) * 4;
     L.off_x = L.off_misc + misc;
     L.off_red = L.off_x + (size_t)L.epad * 4;
-    const size_t red = (size_t)SM_WAVES * SM_LAYER_W * 4;
+    const size_t red = (size_t)waves * SM_LAYER_W * 4;
     L.total = L.off_red + (buf >= red ? 0 : red);            // big buffers: the reduction overlays the dead input buffer
     L.off_y = L.total;
     L.y_lds = L.total + (size_t)L.epad * 8 <= 160 * 1024;    // (the largest complexes recompute them from the flow instead)
@@ -158,13 +162,13 @@ struct SmOp {
     float enc[MAXT][3], v0[MAXT][3], v1[MAXT][3];     // enc: the column as a ready byte offset into an activation buffer (sm_enc; >> 6 = the column)
     int cnt[MAXT], cmax[MAXT];                        // entries of the row, most entries of any row of the tile (wave-uniform)
 };
-template <int MAXT>
+template <int MAXT, int WAVES>
 __device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent, int E,
                                            int nt, int wave, int r16, int q) {
     int j0[MAXT];
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-        const int t = wave + SM_WAVES * k, r = 16 * t + r16;
+        const int t = wave + WAVES * k, r = 16 * t + r16;
         const bool valid = t < nt && r < E;
         j0[k] = valid ? rowptr[r] : 0;
         op.cnt[k] = valid ? rowptr[r + 1] - j0[k] : 0;
@@ -255,8 +259,9 @@ __device__ __forceinline__ void sm_shift_x(const SmOp<MAXT>& op, const int32_t* 
 template <typename F, int... Ks>
 __device__ __forceinline__ void sm_tiles(F&& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
 
-template <int MAXT>
-__global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
+template <int MAXT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
+    constexpr int SM_THREADS = 64 * WAVES, SM_WAVES = WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.n_edges, L = a.n_layers, act = a.act;
     const SmallLds lay = small_lds(E);
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     float* it_s = (float*)(it_e + SM_ITEMS); // [512]
     int* it_d = (int*)(it_s + SM_ITEMS);     // [512]
     float* bh = (float*)(it_d + SM_ITEMS);   // [64][16]
-    float* dwf_red = bh + 64 * SM_C;         // [8][48]
+    float* dwf_red = bh + 64 * SM_C;         // [waves][48]
     float* xs = (float*)(smem + lay.off_x);  // [epad] the input flow of this trajectory
     float2* ysl = (float2*)(smem + lay.off_y);  // [epad] (S_lo x, S_up x), when there is room (lay.y_lds)
     const int n = blockIdx.x, s = n / a.ns, i = n - s * a.ns;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
         ro_y = a.y[(size_t)n * a.max_deg + lane];
     }
     SmOp<MAXT> op;
-    sm_load_op<MAXT>(op, a.rowptr, a.ent, E, nt, wave, r16, q);
+    sm_load_op<MAXT, WAVES>(op, a.rowptr, a.ent, E, nt, wave, r16, q);
 
     // ---------------- layer 1 (one input channel): y = (x, S_lo x, S_up x), H_1 = act(y . W_1)
     for (int e = tid; e < epad; e += SM_THREADS) xs[e] = e < E ? a.x[((size_t)s * E + e) * a.ns + i] : 0.f;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_step_kernel(SmallArgs a) {
     }
     // (the saved activations hs / ys are read back from here on: every store to them has been acknowledged by the L2 at a barrier since --
     //  __syncthreads() waits for the wave's vector-memory counter -- and none of their lines has been loaded into this CU's L1 before)
-    if (!a.same_t) sm_load_op<MAXT>(op, a.rowptr_t, a.ent_t, E, nt, wave, r16, q);      // the backward gathers through the transpose
+    if (!a.same_t) sm_load_op<MAXT, WAVES>(op, a.rowptr_t, a.ent_t, E, nt, wave, r16, q);      // the backward gathers through the transpose
     const float4* ent_b = a.same_t ? a.ent : a.ent_t;
     const int32_t* rowptr_b = a.same_t ? a.rowptr : a.rowptr_t;
     __syncthreads();
@@ -714,7 +719,7 @@ int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, 
     if (!small_shape(conv)) return 0;
     if (n_layers < 2 || n_layers > SM_MAX_LAYERS || hidden != SM_C) return 0;
     if (max_deg <= 0 || max_deg > SM_MAXD || max_items > SM_ITEMS) return 0;
-    if (conv->n_rows > 16 * SM_WAVES * SM_MAXT) return 0;
+    if (conv->n_rows > 16 * 8 * SM_MAXT) return 0;
     return small_lds(conv->n_rows).total <= 160 * 1024 ? 1 : 0;
 }
 
@@ -763,18 +768,20 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     a.loss_part = (double*)ws;
     const SmallLds lay = small_lds(E);
     hipStream_t s = (hipStream_t)stream;
-    const int tiles_per_wave = ((lay.epad >> 4) + SM_WAVES - 1) / SM_WAVES;
-#define SCN_LAUNCH_SMALL(T)                                                                                                   \
+    const int waves = small_waves(E);
+    const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;
+#define SCN_LAUNCH_SMALL(T, WV)                                                                                               \
     do {                                                                                                                      \
         if (lay.total > 64 * 1024)                                                                                            \
-            SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+            SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                             (int)lay.total));                                                                 \
-        hipLaunchKernelGGL(small_step_kernel<T>, dim3(N), dim3(SM_THREADS), lay.total, s, a);                                  \
+        hipLaunchKernelGGL((small_step_kernel<T, WV>), dim3(N), dim3(64 * WV), lay.total, s, a);                               \
     } while (0)
-    if (tiles_per_wave <= 3) SCN_LAUNCH_SMALL(3);
-    else if (tiles_per_wave <= 6) SCN_LAUNCH_SMALL(6);
-    else if (tiles_per_wave <= 8) SCN_LAUNCH_SMALL(8);
-    else SCN_LAUNCH_SMALL(SM_MAXT);
+    if (waves == 12) { if (tiles_per_wave <= 1) SCN_LAUNCH_SMALL(1, 12); else SCN_LAUNCH_SMALL(2, 12); }
+    else if (tiles_per_wave <= 3) SCN_LAUNCH_SMALL(3, 8);
+    else if (tiles_per_wave <= 6) SCN_LAUNCH_SMALL(6, 8);
+    else if (tiles_per_wave <= 8) SCN_LAUNCH_SMALL(8, 8);
+    else SCN_LAUNCH_SMALL(SM_MAXT, 8);
     SCN_LAUNCH_CHECK();
     SmallReduce r{};
     r.n_traj = N; r.pw = pw; r.n_w = 3 * n_layers + 1; r.overwrite = overwrite ? 1 : 0;

@@ -37,7 +37,7 @@ for rep in range(3):
     cyc = (ctypes.c_ulonglong * 16)()
     if lib.scn_debug_small_cycles(cyc) == 0:
         c = [int(v) for v in cyc]
-        print("   tile 1 of wave 0, layer 2 (shader cycles, every phase drained): gather %d, 12 MFMA %d, activation %d, stores %d; whole next tile %d"
-              % (c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4]))
+        print("   tile 1 of wave 0, layer 2 (shader cycles, every phase drained): gather %d, 12 MFMA %d, activation %d, stores %d%s"
+              % (c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], "; whole next tile %d" % (c[5] - c[4]) if c[5] > c[4] else ""))
     for a, b in zip(idx[:-1], idx[1:]):
         print("   %6.2f us  %s" % ((st[b] - st[a]) / 100.0, names.get(a, "")))
