@@ -79,13 +79,14 @@ FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first i
 # Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip), one workgroup per
 # trajectory.  SCN_SMALL_STEP=0 turns it off, =force lifts the rule of small_step_pays() below.  Measured per graph-replayed optimiser
 # step, one launch against the layer-by-layer kernels, ms (tools/small_step.py, profiles/r04_small_step_ab.txt):
-#   |E| =  319:  160 trajectories 0.059 / 0.108   256: 0.061 / 0.118   512: 0.109 / 0.148   1000: 0.197 / 0.198
+#   |E| =  319:  160 trajectories 0.055 / 0.108   256: 0.061 / 0.118   512: 0.109 / 0.148   1000: 0.197 / 0.198
 #   |E| =  639:  100 trajectories 0.086 / 0.110   256: 0.091 / 0.140   512: 0.163 / 0.197
-#   |E| = 1001:  100 trajectories 0.121 / 0.119   200: 0.130 / 0.146   256: 0.134 / 0.150   512: 0.242 / 0.193   1000: 0.471 / 0.302
+#   |E| =  822:  100 trajectories 0.097 / 0.115          |E| = 926:  100 trajectories 0.107 / 0.115
+#   |E| = 1001:  100 trajectories 0.121 / 0.119   128: 0.121 / 0.122   160: 0.123 / 0.144   256: 0.134 / 0.150   512: 0.242 / 0.193
 # One workgroup's chain does not shorten with the batch, so the launch costs (rounds of 256 workgroups) x (chain of this |E|); the layer
 # kernels grow with the work.  At |E| = 1001 the chain is eight row tiles per wave and layer: worth it for a full round, not beyond.
 SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
-SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 768     # six row tiles per wave: beyond, full rounds only
+SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 960     # up to here for any batch of one round
 
 
 def small_step_pays(n_edges, n_traj, n_cus=256):
@@ -93,9 +94,11 @@ def small_step_pays(n_edges, n_traj, n_cus=256):
     rounds = -(-n_traj // n_cus)
     if n_edges <= min(384, SMALL_STEP_MAX_EDGES):
         return rounds <= 4
-    if n_edges <= SMALL_STEP_MAX_EDGES:
+    if n_edges <= min(768, SMALL_STEP_MAX_EDGES):
         return rounds <= 2
-    return rounds == 1 and 2 * n_traj > n_cus
+    if n_edges <= SMALL_STEP_MAX_EDGES:
+        return rounds == 1 or (SMALL_STEP_MAX_EDGES >= (1 << 30) and rounds <= 2)
+    return rounds == 1 and 2 * n_traj >= n_cus
 FUSE_BUNCH = True      # False: per-shift SpMMs + dense-term kernels for every Bunch layer instead of the fused three-level kernels
 FOLD_BUNCH = True      # False: the first two Bunch layers as ordinary layers instead of the rank-one fold (BunchPlan._fold_forward)
 

@@ -221,7 +221,7 @@ def test_host_batches_through_the_replayed_graph_take_the_one_launch_step():
     from scone_gcn_amd import trajectory_experiments as te
     from scone_gcn_amd.complex import SimplicialComplex
     keep = ops.SMALL_STEP_MAX_EDGES
-    ops.SMALL_STEP_MAX_EDGES = 768                                  # the shipped rule, whatever the fixture set
+    ops.SMALL_STEP_MAX_EDGES = 960                                  # the shipped rule, whatever the fixture set
     cx = g.random_SC_graph(130)
     sc = SimplicialComplex(cx)
     N = 160

@@ -453,7 +453,8 @@ def test_one_launch_step_is_taken_where_it_was_measured_to_pay():
     pays = ops.small_step_pays
     assert pays(319, 160) and pays(319, 512) and pays(319, 1000) and not pays(319, 2000)
     assert pays(639, 100) and pays(639, 512) and not pays(639, 1000)
-    assert not pays(1001, 100) and pays(1001, 200) and pays(1001, 256) and not pays(1001, 512)
+    assert pays(822, 100) and pays(926, 100) and not pays(926, 300)
+    assert not pays(1001, 100) and pays(1001, 128) and pays(1001, 200) and pays(1001, 256) and not pays(1001, 512)
     keep = ops.SMALL_STEP_MAX_EDGES
     try:
         ops.SMALL_STEP_MAX_EDGES = 1 << 30               # SCN_SMALL_STEP=force
