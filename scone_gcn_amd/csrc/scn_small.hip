@@ -408,13 +408,15 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     const float* H = lds + in_o;                                 // H_L
     float* dz = lds + out_o;                                     // free buffer -> readout gradient
 
-    // ---------------- readout (TE:151-152, 298-303), cross-entropy (STM:54) and their gradient; wave 0 walks the item list
+    // ---------------- readout (TE:151-152, 298-303), cross-entropy (STM:54) and their gradient.  Wave 0 lists the trajectory's items
+    // (neighbour slot, incident edge, sign), every 16-lane group of the workgroup then takes slots (logits) and later items (scatter);
+    // the softmax in between is one wave's work.
     for (int idx = tid; idx < epad * 4; idx += SM_THREADS) *(f32x4*)(dz + (size_t)idx * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    int total = 0;
+    bool overflow = false;
     if (wave == 0) {
         const int off = sm_excl_scan(ro_cnt, lane);
-        total = __shfl(off + ro_cnt, 63, 64);
-        const bool overflow = total > SM_ITEMS;                  // (the host checks the bound; never index past the list)
+        int total = __shfl(off + ro_cnt, 63, 64);
+        overflow = total > SM_ITEMS;                             // (the host checks the bound; never index past the list)
         if (overflow) total = 0;
         if (lane < a.max_deg) d_ptr[lane] = overflow ? 0 : off;
         if (lane == 0) d_ptr[a.max_deg] = total;
@@ -432,23 +434,23 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
                 it_d[off + j] = lane;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
-        const int g = lane >> 4, cc = lane & 15;
-        const float wc = wlast[cc];
-        for (int d0 = 0; d0 < a.max_deg; d0 += 4) {
-            const int d = d0 + g;
-            float acc = 0.f;
-            if (d < a.max_deg) {
-                const int t0 = d_ptr[d], t1 = d_ptr[d + 1];
-                for (int t = t0; t < t1; ++t) acc = fmaf(it_s[t], H[sm_at1(it_e[t], cc)], acc);
-                bh[d * SM_C + cc] = acc;
-            }
-            float lg = d < a.max_deg ? acc * wc : 0.f;
+    }
+    __syncthreads();
+    const int grp = wave * 4 + (lane >> 4), n_grp = 4 * SM_WAVES, cc = lane & 15;      // 16-lane groups of the workgroup, lane = channel
+    const float wc = wlast[cc];
+    for (int d = grp; d < a.max_deg; d += n_grp) {
+        const int t0 = d_ptr[d], t1 = d_ptr[d + 1];
+        float acc = 0.f;
+        for (int t = t0; t < t1; ++t) acc = fmaf(it_s[t], H[sm_at1(it_e[t], cc)], acc);
+        bh[d * SM_C + cc] = acc;
+        float lg = acc * wc;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
-            if (cc == 0 && d < a.max_deg) lgs[d] = lg;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+        if (cc == 0) lgs[d] = lg;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int g = lane >> 4;
         const bool live = lane < a.max_deg;
         const float logit = live ? lgs[lane] : 0.f;
         const float xm = live ? logit : -INFINITY;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         if (lane == 0) a.loss_part[n] = overflow ? (double)NAN : lpart;
         const float gs = sm_wave_sum(gy);
         if (live) dls[lane] = gy - expf(lp) * gs;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
         // d w_last[c] = sum_d dl[d] * bh[d][c]: lane (g, c) sums the slots d = g, g + 4, ..; the four groups combine in a fixed order
         float dwl = 0.f;
         for (int d = g; d < a.max_deg; d += 4) dwl = fmaf(dls[d], bh[d * SM_C + cc], dwl);
@@ -472,11 +474,10 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     }
     __syncthreads();
     SM_STAMP(9);
-    if (wave == 0) {                                             // dH_L[e][c] += sign * dl[d] * w_last[c]: an edge has two endpoints, so at most
-        const int g = lane >> 4, cc = lane & 15;                 // two addends meet in an entry -- the sum does not depend on their order
-        const float wc = wlast[cc];
+    {                                                            // dH_L[e][c] += sign * dl[d] * w_last[c]: an edge has two endpoints, so at most
+        const int total = d_ptr[a.max_deg];                      // two addends meet in an entry -- the sum does not depend on their order
         const uint32_t dz_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)dz;
-        for (int t = g; t < total; t += 4) {
+        for (int t = grp; t < total; t += n_grp) {
             const uint32_t addr = dz_addr + (uint32_t)sm_at1(it_e[t], cc) * 4u;
             const float v = it_s[t] * dls[it_d[t]] * wc;
             asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");

@@ -79,10 +79,10 @@ FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first i
 # Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip), one workgroup per
 # trajectory.  SCN_SMALL_STEP=0 turns it off, =force lifts the rule of small_step_pays() below.  Measured per graph-replayed optimiser
 # step, one launch against the layer-by-layer kernels, ms (tools/small_step.py, profiles/r04_small_step_ab.txt):
-#   |E| =  319:  160 trajectories 0.055 / 0.108   256: 0.061 / 0.118   512: 0.109 / 0.148   1000: 0.197 / 0.198
+#   |E| =  319:  160 trajectories 0.053 / 0.110   256: 0.061 / 0.118   512: 0.109 / 0.148   1000: 0.197 / 0.198
 #   |E| =  639:  100 trajectories 0.086 / 0.110   256: 0.091 / 0.140   512: 0.163 / 0.197
 #   |E| =  822:  100 trajectories 0.097 / 0.115          |E| = 926:  100 trajectories 0.107 / 0.115
-#   |E| = 1001:  100 trajectories 0.121 / 0.119   128: 0.121 / 0.122   160: 0.123 / 0.144   256: 0.134 / 0.150   512: 0.242 / 0.193
+#   |E| = 1001:  100 trajectories 0.119 / 0.120   128: 0.121 / 0.122   160: 0.123 / 0.144   256: 0.134 / 0.150   512: 0.242 / 0.193
 # One workgroup's chain does not shorten with the batch, so the launch costs (rounds of 256 workgroups) x (chain of this |E|); the layer
 # kernels grow with the work.  At |E| = 1001 the chain is eight row tiles per wave and layer: worth it for a full round, not beyond.
 SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
