@@ -12,9 +12,10 @@ Workload (BASELINE.json metric; configs[3]): synthetic complex with |E| ~ 1M (37
 generator's recipe), hidden = 32, fp32, GLOBAL batch 4096 sharded over the ranks (4096 / N trajectories per GPU ->
 strong scaling; at N = 1 one GPU runs all 4096 as 32 micro-batches of 128).  A step = one optimiser step on a batch
 that is already resident in HBM: forward, loss, backward, RCCL all-reduce of the flat weight-gradient buffer, fused
-ridge + Adam.  Rank 0 prints ONE JSON line.
+ridge + Adam.  Rank 0 prints the full record as `DETAIL {...}` (also written to bench_full.json / --out) and then, as the
+LAST stdout line, ONE compact JSON line of at most 6000 characters (compact_line): the driver keeps an 8 KB tail.
 
-Extra objects in the line (N = 1 only, unless noted):
+Extra objects in the full record (N = 1 only, unless noted; the compact line carries their flat summaries):
   roofline      the kernel FAMILY (template variants summed: the plain and the fused-first backward are one family) that takes
                 the most time in the step, timed live with events on the launch stream: algorithmic bytes of its launches /
                 their duration vs the 8 TB/s HBM peak, every variant's own fraction in `variants`; `traffic` = HBM bytes per
@@ -66,6 +67,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: ranks may share one GPU)")
     ap.add_argument("--skip-modes", default="zeros,field",
                     help="also time the 512-per-GPU step in these zero-skipping modes ('' = none)")
+    ap.add_argument("--out", default="", help="also write the FULL record to this file (e.g. profiles/rNN_bench_1gpu.json)")
     return ap.parse_args()
 
 
@@ -337,6 +339,134 @@ def side_config(name, model, cx, sc, hidden, batch, steps, sync, seed=1030, data
     del net, staged
     torch.cuda.empty_cache()
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the printed record: the driver keeps an 8 KB tail of stdout, so the LAST line is a compact form (<= COMPACT_LIMIT
+# characters) and the full record goes to an earlier `DETAIL {...}` line and to bench_full.json next to this script
+# ----------------------------------------------------------------------------------------------------------------
+
+COMPACT_LIMIT = 6000
+
+
+def _sig(x, digits=5):
+    """Floats to `digits` significant digits (the compact line is for reading and parsing, the full record keeps everything)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _cut(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(line, limit=COMPACT_LIMIT):
+    """The record the driver parses: the headline keys, `config`, a FLAT `roofline` (family fraction, traffic, its variants as
+    strings, the SpMM half of the metric, the dense-random fractions), `cpu_baseline`, the self-validation and one
+    {value, ms_per_step, kernel, frac} entry per side configuration.  Optional parts are dropped, least important first, until
+    the serialised line fits `limit` characters; the headline keys, `roofline` and `cpu_baseline` are never dropped."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: line.get(k) for k in head}
+    cfg = dict(line.get("config") or {})
+    cfg["workload"] = _cut(cfg.get("workload", ""), 220)
+    if cfg.get("collective"):
+        cfg["collective"] = _cut(cfg["collective"], 120)
+    out["config"] = cfg
+    rf = line.get("roofline")
+    if rf:
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step",
+                "algorithmic_bytes_per_launch", "units_per_launch", "share_of_step_kernel_time", "timing", "variant0", "variant1",
+                "variant2", "spmm_dual_frac", "spmm_dual_GBps", "spmm_dual_ms", "spmm_dual_traffic", "spmm_dual_algorithmic_bytes",
+                "dense_random_fwd_frac", "dense_random_fwd_ms", "dense_random_bwd_frac", "dense_random_bwd_ms", "measured_copy_GBps")
+        out["roofline"] = {k: rf[k] for k in keep if k in rf}
+        if rf.get("traffic_source"):
+            out["roofline"]["traffic_source"] = _cut(rf["traffic_source"], 90)
+    else:
+        out["roofline"] = None
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "dtype") if k in cb}
+        out["cpu_baseline"]["sample"] = _cut(cb.get("sample", ""), 260)
+        d0 = cb.get("dense_faithful_configs0")
+        if d0:
+            out["cpu_baseline"]["configs0_dense_faithful_steps_per_s"] = d0.get("optimiser_steps_per_s")
+    else:
+        out["cpu_baseline"] = None
+    out["loss"] = line.get("loss")
+    out["replicas_identical"] = line.get("replicas_identical")
+    par = line.get("parity")
+    if par:
+        out["parity"] = {"max_err": par.get("max_err"), "tol": par.get("tol"), "pass": par.get("pass"), "n": par.get("n")}
+    optional = []                                             # (key, value) in order of importance; dropped from the END
+    cf = {}
+    for name, c in (line.get("configs") or {}).items():
+        r = c.get("roofline") or {}
+        cf[name] = {"value": c.get("value"), "ms_per_step": c.get("ms_per_step"), "kernel": r.get("kernel"), "frac": r.get("frac")}
+        if r.get("traffic"):
+            cf[name]["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
+        if "one_launch_step" in c:
+            cf[name]["one_launch_ms_per_step"] = c["one_launch_step"].get("ms_per_step")
+    if cf:
+        optional.append(("configs", cf))
+    sm = line.get("step_model")
+    if sm:
+        optional.append(("step_model", {"kernel_algorithmic_bytes_per_trajectory": sm.get("kernel_algorithmic_bytes_per_trajectory"),
+                                        "kernel_model_frac_of_hbm_peak_whole_step": sm.get("kernel_model_frac_of_hbm_peak_whole_step")}))
+    ws = line.get("weak_scaling")
+    if ws:
+        optional.append(("weak_scaling", {k: ws.get(k) for k in ("per_gpu_batch", "global_batch", "value", "ms_per_step")}))
+    zs = line.get("zero_skipping")
+    if zs:
+        optional.append(("zero_skipping", {m: {"value": v.get("value"), "ms_per_step": v.get("ms_per_step")} for m, v in zs.items()}))
+    if line.get("kernels"):
+        optional.append(("kernels", {k: [r["launches"], r["avg_ms"]] for k, r in line["kernels"].items()}))
+    val = line.get("validation")
+    if val:
+        optional.append(("validation", {k: val.get(k) for k in ("max_abs_weight_deviation_from_rank0", "weights_sum", "weights_l2",
+                                                                "optimiser_steps_taken")}))
+    out["detail"] = "full record: the preceding 'DETAIL {...}' stdout line and bench_full.json"
+    for k, v in optional:
+        out[k] = v
+    out = _sig(out)
+    for k in ("value", "ms_per_step", "loss"):                # the numbers other records are checked against keep every digit
+        out[k] = line.get(k)
+    while len(json.dumps(out, separators=(",", ":"))) > limit and optional:
+        k, _ = optional.pop()
+        out.pop(k, None)
+    if len(json.dumps(out, separators=(",", ":"))) > limit:      # still too long: strings go next, numbers stay
+        out["config"] = {k: v for k, v in out["config"].items() if not isinstance(v, str) or k == "parallelism"} | {
+            "workload": _cut(out["config"].get("workload", ""), 80)}
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"]["sample"] = _cut(out["cpu_baseline"]["sample"], 80)
+        if out.get("roofline"):
+            out["roofline"].pop("traffic_source", None)
+    return out
+
+
+def emit(line, out_path=None):
+    """Print the full record on a prefixed line, write it to bench_full.json (and `out_path`), then print the compact record
+    as the LAST line of stdout."""
+    full = json.dumps(line)
+    for path in (os.path.join(ROOT, "bench_full.json"), out_path):
+        if path:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+            except OSError as e:                              # a read-only checkout must not cost the measurement
+                sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
+    print("DETAIL " + full)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(line), separators=(",", ":")))
+    sys.stdout.flush()
 
 
 def main():
@@ -631,7 +761,7 @@ def main():
         line["configs"] = configs
 
     if rank == 0:
-        print(json.dumps(line))
+        emit(line, args.out)
     if world > 1:
         dist.destroy_process_group()
 

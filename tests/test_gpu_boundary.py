@@ -358,7 +358,16 @@ def test_bench_lines_of_one_and_two_ranks_agree_on_loss_and_weights():
                "--edges", "50000", "--hidden", "16", "--global-batch", "64", "--steps", "3", "--warmup", "1"]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out_lines = r.stdout.splitlines()
+        # the driver keeps an 8 KB tail of stdout: the LAST line is the compact record, the full one sits on a DETAIL line before it
+        assert out_lines[-1].startswith("{") and len(out_lines[-1]) < 8000, len(out_lines[-1])
+        last = json.loads(out_lines[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "config", "roofline",
+                    "cpu_baseline", "loss", "replicas_identical"):
+            assert key in last, key
+        lines[n] = json.loads([l for l in out_lines if l.startswith("DETAIL {")][-1][len("DETAIL "):])
+        assert last["value"] == lines[n]["value"] and last["loss"] == lines[n]["loss"]
+        assert json.load(open(os.path.join(root, "bench_full.json"))) == lines[n]
     a, b = lines[1], lines[2]
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["config"]["per_gpu_batch"] == 32
     assert a["replicas_identical"] is True and b["replicas_identical"] is True

@@ -446,6 +446,81 @@ def test_bench_roofline_is_per_kernel_family_and_cites_traffic_only_for_the_meas
     assert t == 48.5e9 and "r09_pmc_traffic.json" in src
 
 
+def _synthetic_full_record(n_configs=12, pad=400):
+    """A bench record as large as the largest the script can produce (every optional object present, long strings)."""
+    var = {"launches": 32, "launch_ms": 11.663105249404907, "algorithmic_bytes_per_launch": 49129194308.0, "frac": 0.5265449601265788}
+    roof = {"bound": "hbm", "kernel": "conv_bwd c32->32", "achieved": 3652.8798765176844, "peak": 8000.0, "unit": "GB/s",
+            "frac": 0.4566099845647106, "traffic": 48065196984.0, "launch_ms": 11.493759229779243, "launches_per_step": 64,
+            "algorithmic_bytes_per_launch": 41985321796.0, "units_per_launch": 128, "share_of_step_kernel_time": 0.5431770577135748,
+            "variants": {"conv_bwd c32->32": var, "conv_bwd c32->32 + dW_first": var},
+            "variant0": "conv_bwd c32->32: 0.527 of peak, 11.663 ms x 32", "variant1": "conv_bwd c32->32 + dW_first: 0.385 of peak, 11.324 ms x 32",
+            "traffic_source": "profiles/r04_pmc_traffic.json [main_bench] " + "x" * pad, "measured_copy_GBps": 4601.970897069156,
+            "spmm_dual_frac": 0.6503029651545592, "spmm_dual_GBps": 5202.423721236473, "spmm_dual_ms": 9.44352035522461,
+            "spmm_dual_algorithmic_bytes": 49129194308.0, "spmm_dual_traffic": 53684055637.333336, "spmm_dual_x": "[32, 996634, 128]",
+            "dense_random": {"conv_fwd c32->32": {"ms": 10.2, "GB/s": 3208.1, "frac": 0.401}},
+            "dense_random_fwd_frac": 0.4010171178198363, "dense_random_fwd_ms": 10.224109331766764,
+            "dense_random_bwd_frac": 0.3987552937851131, "dense_random_bwd_ms": 15.400796890258789}
+    kernels = {"conv_fwd c%d->32" % i: {"launches": 32, "avg_ms": 3.3347, "GB/s": 5000.1} for i in range(8)}
+    side = {"workload": "w" * pad, "model": "scone", "value": 5486.308846631601, "ms_per_step": 23.330804659053683, "unit": "trajectories/s",
+            "roofline": dict(roof), "kernels": kernels, "step_model": {"a": 1.0}, "one_launch_step": {"ms_per_step": 0.119, "value": 1.0}}
+    return {"metric": "trajectories/sec fwd+bwd, 3-layer SCoNe |E|~1M batch=4096; SpMM HBM GB/s", "value": 3035.612345678, "unit": "trajectories/s",
+            "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 1349.3123456, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic complex " + "y" * pad, "edges": 996634, "nodes": 369004, "faces": 664069, "hidden": 32,
+                       "global_batch": 4096, "per_gpu_batch": 4096, "micro_batch": 128, "parallelism": "dp1", "collective": "nccl " + "c" * pad,
+                       "batch_seed": 1030, "nnz_lower": 11554450, "nnz_upper": 4981048, "nnz_pattern": 11554450},
+            "roofline": roof,
+            "cpu_baseline": {"value": 0.27999366080219046, "unit": "trajectories/s", "cores": 128, "kind": "port", "dtype": "f32",
+                             "host_cpus": 256, "sample": "s" * (3 * pad), "dense_faithful_configs0": {"optimiser_steps_per_s": 0.29, "sample": "t" * pad}},
+            "replicas_identical": True, "loss": 2.817912345678, "validation": {"loss": 2.8, "replicas_identical": True,
+            "max_abs_weight_deviation_from_rank0": 0.0, "weights_sum": -0.1, "weights_l2": 1.0, "optimiser_steps_taken": 25, "note": "n" * pad},
+            "step_model": {"kernel_algorithmic_bytes_per_trajectory": 1.3e9, "kernel_model_frac_of_hbm_peak_whole_step": 0.49, "note": "n" * pad},
+            "kernels": kernels, "setup_s": 100.0, "weak_scaling": {"per_gpu_batch": 512, "global_batch": 512, "value": 3043.9, "ms_per_step": 168.2},
+            "zero_skipping": {m: {"value": 41115.0, "ms_per_step": 12.4, "note": "z" * pad} for m in ("zeros", "field")},
+            "spmm_dual": {"GB/s": 5202.4}, "parity": {"n": 4, "max_err": 3.4e-7, "tol": 1e-5, "pass": True, "oracle": "o" * pad},
+            "configs": {"config %d %s" % (i, "k" * 20): dict(side) for i in range(n_configs)}}
+
+
+def test_bench_prints_a_compact_last_line_the_driver_can_keep(capsys, tmp_path, monkeypatch):
+    """The driver keeps an 8 KB tail of stdout and parses the last line (round 4's 21.5 KB single line came back `parsed: null`).
+    bench.emit prints the full record on a `DETAIL {...}` line, writes it to bench_full.json / --out, and ends with a compact line of at
+    most bench.COMPACT_LIMIT characters that still carries the headline, `config`, a flat `roofline` and `cpu_baseline`."""
+    import json
+    import bench
+    full = _synthetic_full_record()
+    assert len(json.dumps(full)) > 40000                      # far beyond what the driver keeps
+    for rec in (full, _synthetic_full_record(n_configs=60, pad=2000)):
+        c = bench.compact_line(rec)
+        text = json.dumps(c, separators=(",", ":"))
+        assert len(text) <= bench.COMPACT_LIMIT < 8000, len(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "loss", "replicas_identical"):
+            assert k in c, k
+        assert c["value"] == rec["value"] and c["ms_per_step"] == rec["ms_per_step"] and c["loss"] == rec["loss"]
+        assert c["config"]["workload"] and c["config"]["edges"] == 996634 and "model" not in c["config"]
+        r = c["roofline"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step",
+                  "algorithmic_bytes_per_launch", "units_per_launch", "variant0", "variant1", "spmm_dual_frac", "spmm_dual_ms",
+                  "spmm_dual_traffic", "dense_random_fwd_frac", "dense_random_bwd_frac"):
+            assert k in r, k
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and all(not isinstance(v, (dict, list)) for v in r.values())
+        b = c["cpu_baseline"]
+        assert b["kind"] == "port" and b["cores"] == 128 and b["value"] > 0 and b["sample"]
+    c = bench.compact_line(full)                              # the ordinary record keeps its side configurations
+    assert len(c["configs"]) == 12 and set(next(iter(c["configs"].values()))) >= {"value", "ms_per_step", "kernel", "frac"}
+    # a record without the optional objects (N > 1 ranks, --extras 0) compacts too
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config", "loss", "replicas_identical")}
+    bare.update(roofline=None, cpu_baseline=None)
+    assert bench.compact_line(bare)["roofline"] is None
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full, str(tmp_path / "sub" / "copy.json"))
+    out = capsys.readouterr().out.splitlines()
+    assert out[-2].startswith("DETAIL {") and json.loads(out[-2][7:]) == full
+    assert json.loads(out[-1]) == bench.compact_line(full) and len(out[-1]) <= bench.COMPACT_LIMIT
+    assert json.load(open(tmp_path / "bench_full.json")) == full and json.load(open(tmp_path / "sub" / "copy.json")) == full
+
+
 def test_one_launch_step_is_taken_where_it_was_measured_to_pay():
     """ops.small_step_pays: the size / batch rule of the one-launch small-complex step against the measurements it encodes
     (profiles/r04_small_step_ab.txt, the table above ops.SMALL_STEP)."""
