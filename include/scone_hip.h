@@ -212,9 +212,10 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
  * scn_scatter_flows + the readout / loss in the caller's staging words (typically pinned memory, copied to the device in one transfer):
  *   out = [sample_of: e_cap][edge: e_cap][val: e_cap floats][last_nodes: n_cap][y / total: n_cap x d floats], unused words 0
  * from the ragged flows (ptr [N + 1], edge / val per entry; path_to_flow, SDG:327-344), last_nodes [N] and targets y [N][d] of the
- * whole data set and the batch's trajectory indices traj [m].  Returns the number of flow entries written, SCN_ERR_UNSUPPORTED when
- * the batch does not fit (m > n_cap or more than e_cap entries), or another negative status. */
-int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, const int64_t* ptr, const int32_t* edge, const float* val,
+ * whole data set of n_total trajectories and the batch's trajectory indices traj [m].  Returns the number of flow entries written,
+ * SCN_ERR_UNSUPPORTED when the batch does not fit (m > n_cap or more than e_cap entries), SCN_ERR_BAD_ARG when an index lies outside
+ * [0, n_total) (nothing is read through it), or another negative status. */
+int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, int32_t n_total, const int64_t* ptr, const int32_t* edge, const float* val,
                              const int32_t* last_nodes, const float* y, int32_t d, double total, int32_t e_cap,
                              int32_t n_cap, int32_t* out);
 
@@ -367,7 +368,10 @@ int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, 
  *   W / dW : 3 * n_layers + 1 matrices in the reference's order (TE:139-152), first layer (1, hidden), last (hidden, 1)
  *   max_items : caller's bound on sum_d (incident edges of neighbour d) over the neighbourhood of any last node
  * Served (scn_small_step_supported): hidden = 16, 2 <= n_layers <= 6, max_deg <= 64, max_items <= 512 and 128 * |E| + 64 KB of LDS
- * within 160 KB (|E| <= ~1100); SCN_ERR_UNSUPPORTED otherwise -- the caller then runs the layer-by-layer entry points. */
+ * within 160 KB (|E| <= ~1100); SCN_ERR_UNSUPPORTED otherwise -- the caller then runs the layer-by-layer entry points.
+ * Like every launch here it neither allocates nor copies nor synchronises: the handle's entry pack (col, val_lower, val_upper per
+ * entry) is built by scn_conv_create* for every operator of this shape and size, so the FIRST call on a fresh handle may already be
+ * captured into a HIP graph (tests/test_gpu_small_step.py). */
 int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, int32_t max_deg, int32_t max_items);
 size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers);
 int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,

@@ -17,7 +17,8 @@ P_f32 = ctypes.POINTER(c_f32)
 SCN_MAX_GROUPS = 3
 SCN_MAX_SLOTS = 4
 ACT = {"none": 0, "tanh": 1, "relu": 2, "leaky_relu": 3}
-SCN_ERR_UNSUPPORTED = -4          # include/scone_hip.h
+SCN_ERR_BAD_ARG = -1              # include/scone_hip.h
+SCN_ERR_UNSUPPORTED = -4
 
 
 class WorkListDesc(ctypes.Structure):          # scn_work_list (device pointers)
@@ -64,7 +65,7 @@ SIGNATURES = {
                                                 c_void_p, c_void_p]),
     "scn_node_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
                                                  c_void_p, c_i32, c_void_p, c_void_p]),
-    "scn_host_stage_batch": (c_i64, [c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_double, c_i32,
+    "scn_host_stage_batch": (c_i64, [c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_double, c_i32,
                                      c_i32, c_void_p]),
     "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),

@@ -17,7 +17,7 @@
 //               the activation epilogue's stores are deferred by one slab so the next vmcnt(0) never waits on stores
 //               that were just issued.
 // Parts (one translation unit): scn_blk_layout.inc + scn_blk_plan.inc (host: block plan), scn_blk_common.inc (LDS layout, gather, pipeline helpers),
-// scn_blk_spmm.inc (dual SpMM), scn_blk_fwd.inc / scn_blk_bwd.inc / scn_blk_bwd16.inc (fused layer kernels), scn_blk_first.inc (first-layer
+// scn_blk_spmm.inc (dual SpMM), scn_blk_fwd.inc / scn_blk_bwd.inc (fused layer kernels), scn_blk_first.inc (first-layer
 // gradient streams, reductions), scn_blk_dispatch.inc (host dispatch), scn_terms.inc (fused Bunch layer).
 #include <algorithm>
 #include <array>
@@ -62,7 +62,6 @@ __device__ unsigned long long g_stamps_w[16][10];
 #include "scn_blk_spmm.inc"
 #include "scn_blk_fwd.inc"
 #include "scn_blk_bwd.inc"
-#include "scn_blk_bwd16.inc"
 #include "scn_blk_first.inc"
 #include "scn_blk_dispatch.inc"
 #include "scn_terms.inc"

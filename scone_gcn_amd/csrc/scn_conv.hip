@@ -374,6 +374,7 @@ int scn_conv_create_blocked(int32_t n_rows, int32_t n_groups, const scn_group_de
         }
     }
     int st = build_block_plan(c);
+    if (st == SCN_OK) st = small_prepare(c);
     if (st != SCN_OK) { scn_conv_destroy(c); return st; }
     *out = c;
     return SCN_OK;

@@ -147,6 +147,10 @@ struct scn_conv_s {
     int32_t slot_kind[SCN_MAX_SLOTS] = {0, 0, 0, 0};   // 0 identity, 1 val0, 2 val1
     scn::BlockPlan plan;
     scn::TermsPlan terms;
-    void* small_pack = nullptr;         // (col, val0, val1, 0) per entry for scn_small_step, built on first use (owned through plan.allocs)
+    void* small_pack = nullptr;         // (col, val0, val1, 0) per entry for scn_small_step, built by scn_conv_create* (small_prepare; owned through plan.allocs)
     std::vector<uint8_t> block_start;   // optional layout hint: 1 where a block of the plan must start (see scn_plan_refine_order)
 };
+
+namespace scn {
+int small_prepare(scn_conv_s* c);      // scn_small.hip: the entry pack + LDS limit of scn_small_step, at create time
+}

@@ -658,12 +658,14 @@ int scn_scatter_flows(int32_t n_slabs, int32_t ns, int32_t n_edges, int64_t n_en
 // Host-only: one batch of ragged flows, last nodes and targets into the caller's (pinned) staging words -- what a graph-replayed step
 // copies to the device in ONE transfer.  Plain loops: the same assembly in NumPy was 85 us of a 155 us optimiser step on the
 // reference's own configuration (a dozen array calls on ~1000 elements each).
-int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, const int64_t* ptr, const int32_t* edge, const float* val,
+int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, int32_t n_total, const int64_t* ptr, const int32_t* edge, const float* val,
                              const int32_t* last_nodes, const float* y, int32_t d, double total, int32_t e_cap,
                              int32_t n_cap, int32_t* out) {
-    if (m < 0 || d <= 0 || e_cap <= 0 || n_cap <= 0 || !(total > 0.0)) return SCN_ERR_BAD_SHAPE;
+    if (m < 0 || n_total < 0 || d <= 0 || e_cap <= 0 || n_cap <= 0 || !(total > 0.0)) return SCN_ERR_BAD_SHAPE;
     if (!out || (m > 0 && (!traj || !ptr || !edge || !val || !last_nodes || !y))) return SCN_ERR_BAD_ARG;
     if (m > n_cap) return SCN_ERR_UNSUPPORTED;
+    for (int32_t j = 0; j < m; ++j)
+        if (traj[j] < 0 || traj[j] >= n_total) return SCN_ERR_BAD_ARG;          // an index outside the data set: nothing is read
     int64_t k = 0;
     for (int32_t j = 0; j < m; ++j) k += ptr[traj[j] + 1] - ptr[traj[j]];
     if (k > e_cap) return SCN_ERR_UNSUPPORTED;

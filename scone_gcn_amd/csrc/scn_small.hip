@@ -674,12 +674,24 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
     }
 }
 
-static std::mutex g_pack_mutex;
+static bool small_shape(const scn_conv_s* c) {
+    return c && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 2 && c->g[0].n_cols == c->n_rows;
+}
 
-// (col, val_lower, val_upper, 0) per entry on the device, built on first use and owned by the handle
-static int ensure_pack(scn_conv_s* c, const float4** ent) {
-    std::lock_guard<std::mutex> lock(g_pack_mutex);
-    if (c->small_pack) { *ent = (const float4*)c->small_pack; return SCN_OK; }
+template <int T, int WV>
+static int small_raise_lds(size_t bytes) {
+    SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SCN_OK;
+}
+
+// Called by scn_conv_create* (scn_conv.hip) on every new handle: an operator scn_small_step can serve gets its entry pack
+// (col, val_lower, val_upper, 0) on the device HERE, at create time, and the kernel instance of its size gets its LDS limit raised --
+// so that scn_small_step itself neither allocates nor copies nor synchronises, like every other launch of the library (its first call
+// on a fresh handle can be captured into a HIP graph).  Other operators: nothing to do.
+int small_prepare(scn_conv_s* c) {
+    if (!small_shape(c) || c->n_rows > 16 * 8 * SM_MAXT) return SCN_OK;
+    const SmallLds lay = small_lds(c->n_rows);
+    if (lay.total > 160 * 1024) return SCN_OK;
     const Group& G = c->g[0];
     std::vector<float4> h((size_t)std::max<int64_t>(G.nnz, 1));
     for (int64_t j = 0; j < G.nnz; ++j) {
@@ -693,12 +705,18 @@ static int ensure_pack(scn_conv_s* c, const float4** ent) {
     c->plan.allocs.push_back(d);
     SCN_HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->small_pack = d;
-    *ent = (const float4*)d;
+    if (lay.total > 64 * 1024) {
+        const int waves = small_waves(c->n_rows);
+        const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;
+        int st;
+        if (waves == 12) st = tiles_per_wave <= 1 ? small_raise_lds<1, 12>(lay.total) : small_raise_lds<2, 12>(lay.total);
+        else if (tiles_per_wave <= 3) st = small_raise_lds<3, 8>(lay.total);
+        else if (tiles_per_wave <= 6) st = small_raise_lds<6, 8>(lay.total);
+        else if (tiles_per_wave <= 8) st = small_raise_lds<8, 8>(lay.total);
+        else st = small_raise_lds<SM_MAXT, 8>(lay.total);
+        if (st != SCN_OK) return st;
+    }
     return SCN_OK;
-}
-
-static bool small_shape(const scn_conv_s* c) {
-    return c && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 2 && c->g[0].n_cols == c->n_rows;
 }
 
 }  // namespace scn
@@ -720,7 +738,7 @@ int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, 
     if (!small_shape(conv)) return 0;
     if (n_layers < 2 || n_layers > SM_MAX_LAYERS || hidden != SM_C) return 0;
     if (max_deg <= 0 || max_deg > SM_MAXD || max_items > SM_ITEMS) return 0;
-    if (conv->n_rows > 16 * 8 * SM_MAXT) return 0;
+    if (conv->n_rows > 16 * 8 * SM_MAXT || !conv->small_pack) return 0;     // the pack is built by scn_conv_create* (small_prepare)
     return small_lds(conv->n_rows).total <= 160 * 1024 ? 1 : 0;
 }
 
@@ -749,10 +767,9 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     SmallArgs a{};
     a.n_edges = E; a.ns = ns; a.n_layers = n_layers; a.act = act; a.max_deg = max_deg;
     a.same_t = conv_t == conv ? 1 : 0;
-    int st = ensure_pack(conv, &a.ent);
-    if (st != SCN_OK) return st;
-    st = ensure_pack(conv_t, &a.ent_t);
-    if (st != SCN_OK) return st;
+    if (!conv_t->small_pack) return SCN_ERR_UNSUPPORTED;
+    a.ent = (const float4*)conv->small_pack;
+    a.ent_t = (const float4*)conv_t->small_pack;
     a.rowptr = conv->g[0].d_rowptr;
     a.rowptr_t = conv_t->g[0].d_rowptr;
     a.x = x; a.last_nodes = last_nodes; a.y = y; a.scale = scale;
@@ -771,13 +788,7 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     hipStream_t s = (hipStream_t)stream;
     const int waves = small_waves(E);
     const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;
-#define SCN_LAUNCH_SMALL(T, WV)                                                                                               \
-    do {                                                                                                                      \
-        if (lay.total > 64 * 1024)                                                                                            \
-            SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lay.total));                                                                 \
-        hipLaunchKernelGGL((small_step_kernel<T, WV>), dim3(N), dim3(64 * WV), lay.total, s, a);                               \
-    } while (0)
+#define SCN_LAUNCH_SMALL(T, WV) hipLaunchKernelGGL((small_step_kernel<T, WV>), dim3(N), dim3(64 * WV), lay.total, s, a)
     if (waves == 12) { if (tiles_per_wave <= 1) SCN_LAUNCH_SMALL(1, 12); else SCN_LAUNCH_SMALL(2, 12); }
     else if (tiles_per_wave <= 3) SCN_LAUNCH_SMALL(3, 8);
     else if (tiles_per_wave <= 6) SCN_LAUNCH_SMALL(6, 8);

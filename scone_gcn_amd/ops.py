@@ -74,7 +74,8 @@ def _nbytes(*tensors):
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
-# Module switches for tests and same-box A/B runs (set them from Python; nothing here reads the environment):
+# Module switches for tests and same-box A/B runs (set them from Python; the one environment variable read here is SCN_SMALL_STEP, once,
+# at import):
 FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first instead of the fused-first backward
 # Small complexes: the whole gradient step of a micro-batch in one launch (SconePlan.small_step, csrc/scn_small.hip), one workgroup per
 # trajectory.  SCN_SMALL_STEP=0 turns it off, =force lifts the rule of small_step_pays() below.  Measured per graph-replayed optimiser
@@ -89,8 +90,20 @@ SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
 SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 960     # up to here for any batch of one round
 
 
+_N_CUS = {}
+
+
+def device_cus(device=None):
+    """Compute units of the device the step runs on (256 on a whole MI355X; fewer on a partitioned one), asked once per device."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if idx not in _N_CUS:
+        _N_CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _N_CUS[idx]
+
+
 def small_step_pays(n_edges, n_traj, n_cus=256):
-    """The size rule for the one-launch step (see the table above); n_traj counts the padded trajectories = workgroups."""
+    """The size rule for the one-launch step (see the table above); n_traj counts the padded trajectories = workgroups, n_cus the
+    device's compute units (callers pass device_cus(); the table was measured on 256)."""
     rounds = -(-n_traj // n_cus)
     if n_edges <= min(384, SMALL_STEP_MAX_EDGES):
         return rounds <= 4
@@ -916,7 +929,7 @@ class SconePlan:
             return False
         L = (len(weights) - 1) // 3
         S, E, ns, c_in = x.shape
-        if not small_step_pays(E, S * ns):
+        if not small_step_pays(E, S * ns, device_cus(x.device)):
             return False
         hidden = weights[0].shape[1]
         shapes = [(1, hidden)] * 3 + [(hidden, hidden)] * (3 * (L - 1)) + [(hidden, 1)]
@@ -942,9 +955,8 @@ class SconePlan:
         """Promoted hidden width of this weight list on this plan (None: runs as it is)."""
         if len(weights) < 4 or (len(weights) - 1) % 3 or not self._blocked():
             return None
-        # widths above 32: in 32-channel blocks (_wide_stack) on the fused plan proper (the composed Ebli plan keeps its dense-term path)
-        # (widths above 32: the fused plan runs them in 32-channel blocks, _wide_stack; the composed Ebli plan pads them to a multiple
-        # of 32 as well, so that its dense-term kernels run as 32 x 32 MFMA blocks)
+        # widths above 32 are padded to a multiple of 32 on both plans: the fused plan runs them in 32-channel blocks (_wide_stack), the
+        # composed Ebli plan (PowerPlan) keeps its per-shift structure and runs its dense-term kernels as 32 x 32 MFMA blocks
         return promoted_width([w.shape[1] for w in weights[:-1]], wide=weights[0].shape[0] == 1)
 
     def forward(self, x, last_dev, weights, activity=None):

@@ -85,6 +85,8 @@ class _StaticStage:
         X, e, n = self.X, self.e_cap, self.n_cap
         idx = np.asarray(idx)
         m = len(idx)
+        if m and (int(idx.min()) < 0 or int(idx.max()) >= len(X.ptr) - 1):      # (the native assembler refuses them too)
+            raise IndexError("trajectory index outside the data set of %d trajectories" % (len(X.ptr) - 1))
         starts = X.ptr[idx]
         lens = X.ptr[idx + 1] - starts
         k = int(lens.sum())
@@ -99,7 +101,7 @@ class _StaticStage:
         if self._y_src is not y:
             self._y_src, self._y = y, np.ascontiguousarray(np.asarray(y, np.float32).reshape(len(y), -1))
         traj = np.ascontiguousarray(idx, np.int32)
-        got = _lib.load().scn_host_stage_batch(m, traj.ctypes.data, self._ptr.ctypes.data, self._edge.ctypes.data,
+        got = _lib.load().scn_host_stage_batch(m, traj.ctypes.data, len(self._ptr) - 1, self._ptr.ctypes.data, self._edge.ctypes.data,
                                                self._val.ctypes.data, self._last.ctypes.data, self._y.ctypes.data, self.D,
                                                float(total), e, n, self.host[t].data_ptr())
         if got != k:
@@ -240,6 +242,16 @@ class Scone_GCN():
 
     def _weights_version(self):
         return (int(self._flat_w._version), self._wver)
+
+    def invalidate_eval_cache(self):
+        """Forget the cached evaluation and the staged copies of y / last_nodes.  The caches key on OBJECT IDENTITY and on the two weight
+        version counters: data arrays handed to train() / test() / grad_step() are treated as immutable while the net holds them, and a
+        weight write that neither torch's version counter nor _adam sees (`.data` assignment, a raw-pointer kernel of the caller's) must
+        be followed by this call -- as must an in-place edit of y / last_nodes / the flows."""
+        self._eval = None
+        self._wver += 1
+        for st in self._static.values():
+            st._last_src = st._last = st._y_src = st._y = None
 
     def _eval_all(self, plan, inputs):
         """log-probabilities (N, D, 1) of ALL trajectories of `inputs` under self.weights (device tensor, do not modify)."""

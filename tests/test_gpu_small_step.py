@@ -152,6 +152,66 @@ def test_small_step_inside_the_replayed_graph(cfg1, sc1):
         assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
 
 
+_FIRST_CALL_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from scone_gcn_amd import ops
+from scone_gcn_amd import scone_trajectory_model as stm
+from scone_gcn_amd import synthetic_data_gen as g
+from scone_gcn_amd import trajectory_experiments as te
+from scone_gcn_amd.complex import SimplicialComplex
+ops.SMALL_STEP_MAX_EDGES = 1 << 30
+cx = g.random_SC_graph(250)
+paths = g.generate_random_walks(cx, m=12, seed=3)
+flows, choice, last, _, _ = g.path_dataset(cx, paths, seed=4)
+outs = []
+for captured in (True, False):    # the CAPTURED call comes first: it is the first scn_small_step of this process
+    sc = SimplicialComplex(cx)    # new shifts => a plan on NEW handles (scn_conv_create), no scn_small_step on them yet
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    y = np.zeros((12, sc.max_degree, 1))
+    y[np.arange(12), choice, 0] = 1.0
+    inputs = [readout, last, flows]
+    stm.reseed(1030)
+    net = stm.Scone_GCN(1, 1e-2, 12, 0.0, verbose=False)
+    net.setup(te.MODEL_FUNCS["scone"], [(3, 16)] * 3, shifts, inputs, y, None, np.ones(12, int), model_type="scone")
+    with torch.no_grad():
+        for w in net.weights:
+            w.mul_(20.0)
+    (x, last_d, yt, _), = net.stage(inputs, y, np.arange(12))
+    plan = net._plan(inputs)
+    loss = torch.zeros(1, dtype=torch.float64, device=x.device)
+    torch.cuda.synchronize()
+    if captured:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            assert plan.small_step(x, last_d, yt, -1.0 / 12, net.weights, net._grads, loss, overwrite=True)
+        gr.replay()
+    else:
+        assert plan.small_step(x, last_d, yt, -1.0 / 12, net.weights, net._grads, loss, overwrite=True)
+    torch.cuda.synchronize()
+    outs.append((float(loss), net._flat_g.cpu().numpy().copy()))
+(la, ga), (lb, gb) = outs
+assert la == lb and abs(la) > 1e-3, (la, lb)
+assert np.array_equal(ga, gb) and float(np.abs(ga).max()) > 1e-4
+print("first-call capture ok", la)
+"""
+
+
+def test_first_call_on_a_fresh_handle_can_be_captured_into_a_graph(tmp_path):
+    """include/scone_hip.h: no launch allocates, copies or synchronises.  scn_small_step's entry pack (col, val_lower, val_upper per
+    entry) is built by scn_conv_create*, so the FIRST scn_small_step of a fresh process on a fresh handle can be captured into a HIP
+    graph; the replay equals an eager call on another fresh handle bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "first_call.py"
+    script.write_text(_FIRST_CALL_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "first-call capture ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_small_step_refuses_what_it_does_not_serve(cfg1, sc1):
     """Hidden 32, a complex beyond the LDS, a neighbourhood bound beyond the item list: scn_small_step_supported says no and the
     entry point returns SCN_ERR_UNSUPPORTED (the trainer then runs the layer-by-layer kernels)."""

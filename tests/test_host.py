@@ -558,7 +558,7 @@ def test_native_batch_assembler_fills_the_staging_words_like_the_numpy_reference
     for traj in ([3, 17, 4, 4, 39], [], [0]):
         traj = np.asarray(traj, np.int32)
         out = np.full(n_words, -1, np.int32)
-        got = lib.scn_host_stage_batch(len(traj), traj.ctypes.data, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data,
+        got = lib.scn_host_stage_batch(len(traj), traj.ctypes.data, N, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data,
                                        y.ctypes.data, D, total, e_cap, n_cap, out.ctypes.data)
         ref = np.zeros(n_words, np.int32)
         k = 0
@@ -572,5 +572,9 @@ def test_native_batch_assembler_fills_the_staging_words_like_the_numpy_reference
         assert got == k and np.array_equal(out, ref)
     big = np.arange(N, dtype=np.int32)
     out = np.zeros(n_words, np.int32)
-    assert lib.scn_host_stage_batch(N, big.ctypes.data, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data, y.ctypes.data,
+    assert lib.scn_host_stage_batch(N, big.ctypes.data, N, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data, y.ctypes.data,
                                     D, total, e_cap, n_cap, out.ctypes.data) == _lib.SCN_ERR_UNSUPPORTED
+    for bad in ([3, N], [-1], [2, 5, 1 << 20]):                 # an index outside the data set is refused before anything is read through it
+        traj = np.asarray(bad, np.int32)
+        assert lib.scn_host_stage_batch(len(traj), traj.ctypes.data, N, ptr.ctypes.data, edge.ctypes.data, val.ctypes.data, last.ctypes.data,
+                                        y.ctypes.data, D, total, e_cap, n_cap, out.ctypes.data) == _lib.SCN_ERR_BAD_ARG

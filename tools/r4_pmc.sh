@@ -2,14 +2,16 @@
 # usage (GPU box): tools/r4_pmc.sh <outdir>  -- the rocprofv3 --pmc traffic passes behind bench.py's `roofline.traffic` (FETCH_SIZE, WRITE_SIZE,
 # TCC hit / miss in separate runs: tools/pmc_run.sh), one section per launch shape, merged by tools/pmc_merge.py into <outdir>/pmc_traffic.json
 # and stamped there with the hash of the kernel sources the passes ran on (copy it to profiles/rNN_pmc_traffic.json).
-OUT=$1
-mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
+OUT=${1:?usage: tools/r4_pmc.sh <outdir>}
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
 step() {
   local name=$1 limit=$2; shift 2
   local t0=$(date +%s)
-  timeout -k 10 $limit "$@" > $OUT/$name.log 2>&1
-  local rc=$?
+  local rc=0
+  timeout -k 10 $limit "$@" > $OUT/$name.log 2>&1 || rc=$?
   echo "$name rc=$rc $(( $(date +%s) - t0 ))s" | tee -a $OUT/status.txt
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed at its limit: stopping" | tee -a $OUT/status.txt; exit 1; fi
 }
