@@ -217,7 +217,7 @@ def time_config(net, inputs, staged, total, steps, warmup, sync, all_max):
 def family(key):
     """Timer key -> kernel family: the template variants of one kernel (the fused-first backward `+ dW_first`, the
     `(dW only)` form) are one family; different kernels (first layer c1->C vs the fused C->C) are not."""
-    return key.replace(" + dW_first", "").replace(" (dW only)", "")
+    return key.replace(" + dW_first", "").replace(" (dW only)", "").replace(" + partial", "")
 
 
 def dominant(table):

@@ -97,6 +97,17 @@ int scn_conv_forward(scn_conv_t conv, int32_t n_slabs, int32_t ns,
                      const float* const* W, int32_t c_out, int32_t act,
                      float* out, void* stream);
 
+/* The same with a tensor of partial pre-activations added before the activation:
+ *   out[s,r,n,:] = act( partial[s,r,n,:] + sum_over_slots (...) @ W_slot )      partial: device [n_slabs][n_rows][ns][c_out]
+ * `partial` may be `out` itself (in place).  This is how a layer wider than 32 channels adds up its (input block, output block)
+ * pairs of 32 channels (-hidden_layers takes any width, TE:103-110) without a summation pass of its own: the first pair of an output
+ * block runs scn_conv_forward with SCN_ACT_NONE, the last one this entry point with the layer's activation.  Served for one group,
+ * c_in = c_out = 32, ns = 4 on an LDS-blocked plan; SCN_ERR_UNSUPPORTED otherwise. */
+int scn_conv_forward_accumulate(scn_conv_t conv, int32_t n_slabs, int32_t ns,
+                                const float* const* src, const int32_t* c_in,
+                                const float* const* W, int32_t c_out, int32_t act,
+                                const float* partial, float* out, void* stream);
+
 /* Backward of one INPUT level (what jax.grad generates for the same loops, STM:307).  `conv_t` is the
  * operator whose slots are the TRANSPOSED shifts feeding this input level (for scone's symmetric
  * L_lower / L_upper it is the forward object itself).
@@ -114,6 +125,16 @@ int scn_conv_backward(scn_conv_t conv_t, int32_t n_slabs, int32_t ns,
                       const float* const* W, const float* aux, int32_t c_aux, int32_t act,
                       float* dx, float* const* dW,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same with a partial input gradient added:  dx = dx_partial + ( sum_slots G_slot @ W_slot^T ) * act'(aux)
+ * (dx_partial: device [n_slabs][n_rows][ns][c_aux]; may be `dx` itself).  The backward counterpart of scn_conv_forward_accumulate: the
+ * input gradient of an input block of a layer wider than 32 channels is the sum over the layer's output blocks (act' of the layer
+ * below is a common factor).  Served for one group, c_dz = c_aux = 32, ns = 4 on an LDS-blocked plan; SCN_ERR_UNSUPPORTED otherwise. */
+int scn_conv_backward_accumulate(scn_conv_t conv_t, int32_t n_slabs, int32_t ns,
+                                 const float* const* dz, const int32_t* c_dz,
+                                 const float* const* W, const float* aux, int32_t c_aux, int32_t act,
+                                 const float* dx_partial, float* dx, float* const* dW,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* The two Hodge shifts alone: ya = val0-operator * x, yb = val1-operator * x on group 0 of `conv`
  * (the L_down X / L_up X products of TE:146-147 without the dense part; the SpMM GB/s metric).
@@ -379,6 +400,13 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
                    int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
                    const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* Readout of a last layer kept as channel blocks (hidden widths above 32): logits are linear in H, so the blocks' logits
+ * (scn_readout_forward per block with its rows of W_last) are added and normalised here:
+ *   logits[n,:] = sum_k logits_parts[k][n,:],   logp = logits - logsumexp_d(logits)   (all D entries, padding included: TE:151-152)
+ * n_parts <= 4; logits may be logits_parts[0]. */
+int scn_logits_sum_log_softmax(int32_t n_traj, int32_t max_deg, int32_t n_parts, const float* const* logits_parts,
+                               float* logits, float* logp, void* stream);
 
 /* Masked cross-entropy of one micro-batch (the data term of STM:54 and its gradient w.r.t. the log-probabilities):
  *   d_logp[i] = y[i] * scale   (scale = -1 / number of trajectories in the GLOBAL batch; padding rows have y = 0)

@@ -65,6 +65,7 @@ SIGNATURES = {
                                                 c_void_p, c_void_p]),
     "scn_node_readout_backward": (ctypes.c_int, [c_i32, c_i32, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
                                                  c_void_p, c_i32, c_void_p, c_void_p]),
+    "scn_logits_sum_log_softmax": (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     "scn_host_stage_batch": (c_i64, [c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_double, c_i32,
                                      c_i32, c_void_p]),
     "scn_scatter_flows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -82,9 +83,14 @@ SIGNATURES = {
     "scn_conv_backward_power": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                                c_void_p, c_i32, c_i32, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
                                                c_size_t, c_void_p]),
+    "scn_conv_forward_accumulate": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                                   ctypes.POINTER(c_void_p), c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "scn_conv_forward_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
                                              ctypes.POINTER(c_void_p), c_i32, c_i32, c_void_p,
                                              ctypes.POINTER(WorkListDesc), c_void_p]),
+    "scn_conv_backward_accumulate": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
+                                                    ctypes.POINTER(c_void_p), c_void_p, c_i32, c_i32, c_void_p, c_void_p,
+                                                    ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "scn_conv_backward_list": (ctypes.c_int, [c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p), P_i32,
                                               ctypes.POINTER(c_void_p), c_void_p, c_i32, c_i32, c_void_p,
                                               ctypes.POINTER(c_void_p), c_void_p, c_size_t,

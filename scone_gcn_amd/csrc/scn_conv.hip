@@ -20,12 +20,13 @@ void free_block_plan(scn_conv_s* c);
 bool blocked_forward_supported(const scn_conv_s* c, int ns, const int32_t* c_in, int c_out);
 int blocked_forward(scn_conv_s* c, int n_slabs, int ns, const float* const* src, const int32_t* c_in,
                     const float* const* W, int c_out, int act, float* out, float* y_out, const WorkList* wl,
-                    hipStream_t st);
+                    hipStream_t st, const float* partial = nullptr);
 bool blocked_backward_supported(const scn_conv_s* c, int ns, const int32_t* c_dz, int c_aux, bool has_dx);
 size_t blocked_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, const int32_t* c_dz, int c_aux);
 int blocked_backward(scn_conv_s* c, int n_slabs, int ns, const float* const* dz, const int32_t* c_dz,
                      const float* const* W, const float* aux, int c_aux, int act, float* dx,
-                     float* const* dW, void* ws, size_t ws_bytes, const WorkList* wl, hipStream_t st);
+                     float* const* dW, void* ws, size_t ws_bytes, const WorkList* wl, hipStream_t st,
+                     const float* dx_partial = nullptr);
 bool blocked_spmm_supported(const scn_conv_s* c, int k);
 bool blocked_power_supported(const scn_conv_s* c, int ns, int ch);
 size_t blocked_power_backward_workspace(const scn_conv_s* c, int n_slabs, int ns, int ch);
@@ -492,6 +493,18 @@ int scn_conv_forward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* con
     return scn_conv_forward_list(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, stream);
 }
 
+int scn_conv_forward_accumulate(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
+                                const float* const* W, int32_t c_out, int32_t act, const float* partial, float* out, void* stream) {
+    if (!c || !src || !c_in || !W || !out || !partial) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || c_out <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (n_slabs > 65535) return SCN_ERR_UNSUPPORTED;
+    if (!src[0] || c_in[0] <= 0) return SCN_ERR_BAD_ARG;
+    for (int s = 0; s < c->n_slots; ++s)
+        if (!W[s]) return SCN_ERR_BAD_ARG;
+    if (c->n_groups != 1 || c_in[0] != 32 || c_out != 32 || !blocked_forward_supported(c, ns, c_in, c_out)) return SCN_ERR_UNSUPPORTED;
+    return blocked_forward(c, n_slabs, ns, src, c_in, W, c_out, act, out, nullptr, nullptr, (hipStream_t)stream, partial);
+}
+
 int scn_conv_forward_list(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* src, const int32_t* c_in,
                           const float* const* W, int32_t c_out, int32_t act, float* out, const scn_work_list* wl,
                           void* stream) {
@@ -625,6 +638,18 @@ int scn_conv_backward(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* co
                       float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
     return scn_conv_backward_list(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes, nullptr,
                                   stream);
+}
+
+int scn_conv_backward_accumulate(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,
+                                 const float* const* W, const float* aux, int32_t c_aux, int32_t act, const float* dx_partial,
+                                 float* dx, float* const* dW, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !dz || !c_dz || !W || !aux || !dW || !workspace || !dx || !dx_partial) return SCN_ERR_BAD_ARG;
+    if (n_slabs <= 0 || ns <= 0 || c_aux <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
+    if (!dz[0] || c_dz[0] <= 0) return SCN_ERR_BAD_ARG;
+    if (c->n_groups != 1 || c_dz[0] != 32 || c_aux != 32 || !blocked_backward_supported(c, ns, c_dz, c_aux, true)) return SCN_ERR_UNSUPPORTED;
+    if (workspace_bytes < scn_conv_backward_workspace(c, n_slabs, ns, c_dz, c_aux)) return SCN_ERR_WORKSPACE;
+    return blocked_backward(c, n_slabs, ns, dz, c_dz, W, aux, c_aux, act, dx, dW, workspace, workspace_bytes, nullptr,
+                            (hipStream_t)stream, dx_partial);
 }
 
 int scn_conv_backward_list(scn_conv_t c, int32_t n_slabs, int32_t ns, const float* const* dz, const int32_t* c_dz,

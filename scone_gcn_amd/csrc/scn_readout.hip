@@ -504,6 +504,29 @@ __global__ void scatter_flows_kernel(int ns, int n_edges, int64_t n_entries, con
 
 // masked cross-entropy of STM:54 for one micro-batch: d_logp = y * scale (scale = -1 / global batch size) and
 // loss[0] += sum logp * d_logp in fp64, one block, fixed summation order
+// logp[n][:] = z - logsumexp(z), z = sum over the parts of logits_k[n][:]  (one wave per trajectory, lanes stride over the slots)
+struct LogitParts { const float* p[4]; };
+__global__ __launch_bounds__(64) void logits_sum_log_softmax_kernel(int max_deg, int n_parts, LogitParts L, float* __restrict__ logits,
+                                                                    float* __restrict__ logp) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const size_t base = (size_t)n * max_deg;
+    float m = -INFINITY;
+    for (int d = lane; d < max_deg; d += 64) {
+        float z = L.p[0][base + d];
+        if (n_parts > 1) z += L.p[1][base + d];
+        if (n_parts > 2) z += L.p[2][base + d];
+        if (n_parts > 3) z += L.p[3][base + d];
+        logits[base + d] = z;
+        m = fmaxf(m, z);
+    }
+    m = wave_max(m);
+    float se = 0.f;
+    for (int d = lane; d < max_deg; d += 64) se += expf(logits[base + d] - m);       // (this lane's own stores)
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    for (int d = lane; d < max_deg; d += 64) logp[base + d] = logits[base + d] - lse;
+}
+
 __global__ __launch_bounds__(1024) void masked_ce_kernel(int64_t n, const float* __restrict__ logp,
                                                          const float* __restrict__ y, float scale,
                                                          float* __restrict__ d_logp, double* __restrict__ loss) {
@@ -688,6 +711,20 @@ int64_t scn_host_stage_batch(int32_t m, const int32_t* traj, int32_t n_total, co
         for (int32_t c = 0; c < d; ++c) yo[(size_t)j * d + c] = (float)((double)y[(size_t)n * d + c] / total);
     }
     return k;
+}
+
+int scn_logits_sum_log_softmax(int32_t n_traj, int32_t max_deg, int32_t n_parts, const float* const* logits_parts, float* logits,
+                               float* logp, void* stream) {
+    if (n_traj <= 0 || max_deg <= 0 || n_parts <= 0 || n_parts > 4) return SCN_ERR_BAD_SHAPE;
+    if (!logits_parts || !logits || !logp) return SCN_ERR_BAD_ARG;
+    LogitParts L{};
+    for (int k = 0; k < n_parts; ++k) {
+        if (!logits_parts[k]) return SCN_ERR_BAD_ARG;
+        L.p[k] = logits_parts[k];
+    }
+    hipLaunchKernelGGL(logits_sum_log_softmax_kernel, dim3(n_traj), dim3(64), 0, (hipStream_t)stream, max_deg, n_parts, L, logits, logp);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
 }
 
 int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, void* stream) {

@@ -205,10 +205,14 @@ class ConvOp:
         check(_lib.load().scn_conv_plan_info(self.handle, ctypes.byref(nb), ctypes.byref(ms)), "scn_conv_plan_info")
         return nb.value, ms.value
 
-    def forward(self, srcs, Ws, c_out, act, out=None, wl=None):
-        """wl: WorkList (zero-skipping): only the listed items of `out` are written; `out` must be given, all-zero."""
+    def forward(self, srcs, Ws, c_out, act, out=None, wl=None, partial=None):
+        """wl: WorkList (zero-skipping): only the listed items of `out` are written; `out` must be given, all-zero.
+        partial: tensor of the output's shape added to the pre-activation (scn_conv_forward_accumulate; out defaults to it, in place)."""
         lib = _lib.load()
         assert wl is None or out is not None
+        if partial is not None:
+            assert wl is None and tuple(partial.shape) == (srcs[0].shape[0], self.n_rows, srcs[0].shape[2], c_out)
+            out = partial if out is None else out
         S, ns = srcs[0].shape[0], srcs[0].shape[2]
         assert len(srcs) == self.n_groups and len(Ws) == self.n_slots
         c_in = []
@@ -219,17 +223,27 @@ class ConvOp:
             assert tuple(w.shape) == (c_in[self.slot_group[s]], c_out), "weight shape"
         if out is None:
             out = torch.empty((S, self.n_rows, ns, c_out), device=srcs[0].device, dtype=torch.float32)
+        if partial is not None:
+            with _timed("conv_fwd c%s->%d + partial" % ("+".join(map(str, c_in)), c_out), _nbytes(out, partial, *srcs) + self.csr_bytes):
+                check(lib.scn_conv_forward_accumulate(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
+                                                      ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(partial), _dev(out),
+                                                      _stream()), "scn_conv_forward_accumulate")
+            return out
         with _timed("conv_fwd c%s->%d" % ("+".join(map(str, c_in)), c_out), None if wl is not None else _nbytes(out, *srcs) + self.csr_bytes):
             check(lib.scn_conv_forward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in srcs]), i32_array(c_in),
                                             ptr_array([_dev(w).value for w in Ws]), c_out, ACT[act], _dev(out),
                                             wl.ref() if wl is not None else None, _stream()), "scn_conv_forward")
         return out
 
-    def backward(self, dzs, Ws, aux, act, need_dx, dWs, dx=None, wl=None):
+    def backward(self, dzs, Ws, aux, act, need_dx, dWs, dx=None, wl=None, dx_partial=None):
         """dWs: list of tensors ACCUMULATED into.  Returns dx or None.  wl: WorkList (zero-skipping): only the listed
-        items of `dx` are written (it must be given, all-zero) and only they contribute to dWs."""
+        items of `dx` are written (it must be given, all-zero) and only they contribute to dWs.
+        dx_partial: tensor of dx's shape ADDED to the input gradient (scn_conv_backward_accumulate; dx defaults to it, in place)."""
         lib = _lib.load()
         assert wl is None or (dx is not None or not need_dx)
+        if dx_partial is not None:
+            assert wl is None and need_dx and tuple(dx_partial.shape) == tuple(aux.shape)
+            dx = dx_partial if dx is None else dx
         S, ns, c_aux = aux.shape[0], aux.shape[2], aux.shape[3]
         assert aux.shape[1] == self.n_rows and len(dzs) == self.n_groups
         c_dz = []
@@ -243,6 +257,14 @@ class ConvOp:
         ws = torch.empty(max(int(nbytes), 256), device=aux.device, dtype=torch.uint8)
         if need_dx and dx is None:
             dx = torch.empty_like(aux)
+        if dx_partial is not None:
+            with _timed("conv_bwd c%s->%d + partial" % ("+".join(map(str, c_dz)), c_aux), _nbytes(aux, dx, dx_partial, *dzs) + self.csr_bytes):
+                check(lib.scn_conv_backward_accumulate(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
+                                                       ptr_array([_dev(w).value for w in Ws]), _dev(aux), c_aux, ACT[act],
+                                                       _dev(dx_partial), _dev(dx), ptr_array([_dev(d).value for d in dWs]),
+                                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                      "scn_conv_backward_accumulate")
+            return dx
         with _timed("conv_bwd c%s->%d%s" % ("+".join(map(str, c_dz)), c_aux, "" if need_dx else " (dW only)"),
                     None if wl is not None else _nbytes(aux, dx if need_dx else None, *dzs) + self.csr_bytes):
             check(lib.scn_conv_backward_list(self.handle, S, ns, ptr_array([_dev(x).value for x in dzs]), cdz,
@@ -965,9 +987,16 @@ class SconePlan:
         w = wp if P else weights
         if P and P > 32 and type(self) is SconePlan:
             hs, y0 = self._wide_stack(x, w, P)
-            H = torch.cat(hs[-1], dim=3)                # the readout reads one (S, E, ns, P) tensor
-            logp, bh, _ = self.readout(H, w[-1], last_dev)
-            return logp, (hs, bh, y0, None, wp, H)
+            # the readout is linear in H: block by block with the block's rows of W_last, the logits added and normalised in one launch
+            bhs, parts = [], []
+            for j, Hj in enumerate(hs[-1]):
+                _, bh, lg = self.readout(Hj, w[-1][32 * j:32 * j + 32], last_dev)
+                bhs.append(bh)
+                parts.append(lg)
+            logp = torch.empty_like(parts[0])
+            check(_lib.load().scn_logits_sum_log_softmax(logp.shape[0], self.max_deg, len(parts), ptr_array([_dev(t).value for t in parts]),
+                                                         _dev(parts[0]), _dev(logp), _stream()), "scn_logits_sum_log_softmax")
+            return logp, (hs, bhs, y0, None, wp, "wide")
         hs, y0 = self.conv_stack(x, w, activity)
         logp, bh, _ = self.readout(hs[-1], w[-1], last_dev)
         return logp, (hs, bh, y0, activity, wp)
@@ -995,19 +1024,24 @@ class SconePlan:
                     outs.append(first[0])
                     y0 = first[1] if y0 is None else y0
                 else:
-                    parts = [self.conv.forward([prev[i]], [self._wblock(Ws, i, j) for Ws in W], 32,
-                                               self.act if len(prev) == 1 else "none") for i in range(len(prev))]
-                    outs.append(parts[0] if len(parts) == 1 else sum_act(parts, self.act))
+                    # input block by input block INTO the output block: the partial pre-activation of the blocks before is added
+                    # inside the next launch (scn_conv_forward_accumulate, in place), the last launch applies the activation
+                    acc = None
+                    for i in range(len(prev)):
+                        last = i == len(prev) - 1
+                        acc = self.conv.forward([prev[i]], [self._wblock(Ws, i, j) for Ws in W], 32, self.act if last else "none",
+                                                partial=acc)
+                    outs.append(acc)
             hs.append(outs)
         return hs, y0
 
     def _wide_backward(self, saved, logp, d_logp, last_dev, w, grads):
-        hs, bh, y0, _, _, H = saved
-        P = H.shape[3]
-        k, L = P // 32, len(hs) - 1
-        dz_top, key = self._readout_grad(H, bh, logp, d_logp, last_dev, w, grads)
-        dzs = [dz_top[..., 32 * j:32 * j + 32].contiguous() for j in range(k)]
-        self._release_top(dz_top, key, last_dev)
+        hs, bhs, y0, _, _, _ = saved
+        k, L = len(hs[-1]), len(hs) - 1
+        # the readout's gradient block by block (d_logits depends on the summed logits only), each into its own pooled all-zero buffer
+        tops = [self._readout_grad(hs[-1][j], bhs[j], logp, d_logp, last_dev, [w[-1][32 * j:32 * j + 32]], [grads[-1][32 * j:32 * j + 32]])
+                for j in range(k)]
+        dzs = [t[0] for t in tops]
         for l in reversed(range(L)):
             W, G = w[3 * l:3 * l + 3], grads[3 * l:3 * l + 3]
             if l == 0:                                  # dW_s[0, j] = sum_p (S_s x)[p] dz_j[p]: one stream over dz per block
@@ -1016,16 +1050,23 @@ class SconePlan:
                     assert self.conv.dw_first(hs[0][0], y0, dzs[j], gj)
                     for Gs, g in zip(G, gj):
                         Gs[:, 32 * j:32 * j + 32] += g
+                if L == 1:                              # (a single wide layer: the readout gradients were this layer's dz)
+                    for dz_top, key in tops:
+                        self._release_top(dz_top, key, last_dev)
                 break
             new = []
             for i in range(len(hs[l])):
-                parts = []
+                acc = None                              # output block by output block INTO the input block's gradient (in place)
                 for j in range(k):
                     gij = [torch.zeros((32, 32), device=self.device, dtype=torch.float32) for _ in range(3)]
-                    parts.append(self.conv_T.backward([dzs[j]], [self._wblock(Ws, i, j) for Ws in W], hs[l][i], self.act, True, gij))
+                    acc = self.conv_T.backward([dzs[j]], [self._wblock(Ws, i, j) for Ws in W], hs[l][i], self.act, True, gij,
+                                               dx_partial=acc)
                     for Gs, g in zip(G, gij):
                         Gs[32 * i:32 * i + 32, 32 * j:32 * j + 32] += g
-                new.append(parts[0] if len(parts) == 1 else sum_act(parts, "none"))
+                new.append(acc)
+            if l == L - 1:                              # the top layer is done with the readout gradients: wipe and keep them
+                for dz_top, key in tops:
+                    self._release_top(dz_top, key, last_dev)
             dzs = new
         return grads
 
@@ -1035,9 +1076,8 @@ class SconePlan:
         lib = _lib.load()
         S, E, ns, C = H.shape
         key = (S, E, ns, C)
-        dz_top = self._dz_zero.pop(key, None)
-        if dz_top is None:
-            dz_top = torch.zeros_like(H)
+        pool = self._dz_zero.get(key)
+        dz_top = pool.pop() if pool else torch.zeros_like(H)
         d_logits = torch.empty_like(logp)
         d_logp = d_logp.contiguous()
         check(lib.scn_readout_backward(S, ns, E, C, _dev(H), _dev(weights[-1]), _dev(self.nbr, torch.int32),
@@ -1054,13 +1094,13 @@ class SconePlan:
         S, E, ns, C = key
         if dz_top.numel() * 4 <= self.SMALL_DZ_BYTES:
             dz_top.zero_()
-            self._dz_zero[key] = dz_top
+            self._dz_zero.setdefault(key, []).append(dz_top)
             return
         check(_lib.load().scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
                                                _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),
                                                _dev(self.inc_edge, torch.int32), _dev(self.edge_nodes, torch.int32),
                                                _dev(dz_top), _stream()), "scn_readout_clear_dz")
-        self._dz_zero[key] = dz_top
+        self._dz_zero.setdefault(key, []).append(dz_top)
 
     def backward(self, saved, logp, d_logp, last_dev, weights, grads):
         """grads: list of tensors (same shapes as weights) accumulated into."""

@@ -75,7 +75,7 @@ def test_dense_shifts_and_a_plain_bcond_closure_run_unchanged(cfg1, model):
     assert _maxdiff(out.detach().cpu().numpy(), ref) <= TOL
     loss = -(out * torch.as_tensor(y, dtype=torch.float32, device="cuda")).sum() / len(sel)
     loss.backward()
-    assert abs(float(loss.detach()) - ref_loss) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL * max(1.0, abs(ref_loss))     # (relative, like _maxdiff: fp32 resolves a loss of 35 to 4e-6)
     for a, b in zip(wt, ref_g):
         assert _maxdiff(a.grad.cpu().numpy(), b) <= TOL
     # second call: other last nodes (the closure is probed for the new ones), per-sample call, and the trainer surface
@@ -96,7 +96,7 @@ def test_dense_shifts_and_a_plain_bcond_closure_run_unchanged(cfg1, model):
     net.grad_step([readout, last, X], y, mask, apply=False)
     for a, b in zip(net._grads, ref_g):
         assert _maxdiff(a.cpu().numpy(), b) <= TOL
-    assert abs(net.loss(net.weights, [readout, last, X], y, mask) - ref_loss) <= TOL
+    assert abs(net.loss(net.weights, [readout, last, X], y, mask) - ref_loss) <= TOL * max(1.0, abs(ref_loss))
 
 
 def test_repeated_flow_entries_accumulate(cfg1):
