@@ -128,6 +128,7 @@ SIGNATURES = {
 }
 
 _lib = None
+AB_OLDER_LIBRARY = False              # set by tools/ab_run.py: tolerate entry points a build from an older revision does not have
 
 
 class SconeHipError(RuntimeError):
@@ -148,6 +149,8 @@ def load():
             f"(or __graft_entry__.build()). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if AB_OLDER_LIBRARY and not hasattr(lib, name):
+            continue                  # tools/ab_run.py only: an older build of the library as the "before" side of an A/B
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args

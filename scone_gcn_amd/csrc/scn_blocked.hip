@@ -12,8 +12,8 @@
 //     for slab: [s_waitcnt vmcnt(0); s_barrier]  -> slab s has landed in buffer s&1, everybody left buffer (s+1)&1
 //               issue LDS-DMA (global_load_lds, 16 B/lane, per-lane source = gather) of slab s+1 into the other buffer
 //               compute slab s: each wave gathers its rows x 4 trajectories with lane = (point, channel slice)
-//               from the XOR-swizzled LDS image and feeds [self | lower | upper] into bf16 MFMAs on an EXACT three-way
-//               split (hi + mid + lo = the fp32 value, six products, fp32 accumulation) against split weights in LDS;
+//               from the XOR-swizzled LDS image and feeds [self | lower | upper] into f16 MFMAs on a two-way hi + lo split under
+//               power-of-two row scales (three products, fp32 accumulation: scn_blk_fwd.inc) against split weights in LDS;
 //               the activation epilogue's stores are deferred by one slab so the next vmcnt(0) never waits on stores
 //               that were just issued.
 // Parts (one translation unit): scn_blk_layout.inc + scn_blk_plan.inc (host: block plan), scn_blk_common.inc (LDS layout, gather, pipeline helpers),

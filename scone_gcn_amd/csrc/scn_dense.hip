@@ -429,7 +429,7 @@ __global__ void dense_dw_reduce(DenseReduceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The first TWO Bunch layers without a 32-channel gather (scn_split_sign / scn_fold1_*; derivation in DESIGN.md):
+// The first TWO Bunch layers without a 32-channel gather (scn_split_sign / scn_fold1_*; derivation in profiles/HISTORY.md section 3.1):
 // bunch_func starts from [0, flow, 0] (TE:179), so the first layer's output of every level is relu of ONE rank-one term,
 //   H1_j[p][:] = relu(g_j[p] w_j) = max(g_j[p], 0) relu(w_j) + min(g_j[p], 0) min(w_j, 0),        g_j = S x  (one channel)
 // and the second layer's pre-activation is a sum of rank-one terms of SHIFTED SCALARS:

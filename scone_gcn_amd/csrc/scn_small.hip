@@ -2,7 +2,7 @@
 //
 // The reference's own problem sizes (TE:86-90: |E| = 1001, batch 100; the drifter data set: |E| = 320) are launch-bound on the
 // layer-by-layer kernels: five fused conv launches, readout, cross-entropy and their reductions are ~17 launches of 4-18 us
-// each per optimiser step, and what every launch does is a chain of a few dependent L2 round trips.
+// each per optimiser step (profiles/HISTORY.md section 3.4), and what every launch does is a chain of a few dependent L2 round trips.
 // Trajectories do not interact (TE:256 vmap) -- only the weight gradient sums over them -- and on a complex this small ONE
 // trajectory's activation tensor (|E| x 16 floats) fits the LDS of a CU.  So: one workgroup per trajectory runs every layer,
 // the readout, the cross-entropy and the whole backward on LDS-resident activations, with workgroup barriers between layers and

@@ -1006,7 +1006,7 @@ class SconePlan:
     # the partial pre-activations of an output block are added and activated by scn_sum_act; in the backward the partial input
     # gradients of an input block add up likewise (act' of the layer below is a common factor of the partial results).  The
     # same products in the same association order per 32 x 32 weight block; ~4x the hidden-32 step at hidden 64 instead of the
-    # generic one-row-per-workgroup kernels (measured 236x).
+    # generic one-row-per-workgroup kernels (measured 236x, profiles/HISTORY.md section 3.3).
     @staticmethod
     def _wblock(W, i, j):
         r = slice(None) if W.shape[0] == 1 else slice(32 * i, 32 * i + 32)

@@ -361,7 +361,7 @@ class Scone_GCN():
         rows = sum(plan.sizes) if self.model_type == 'bunch' else plan.n_edges
         budget = None
         if self.model_type == 'bunch' and ops.FOLD_BUNCH and len(widths) > 3 and widths[1] == widths[2] == 32:
-            # the first hidden layer is never materialised (rank-one fold) and levels the loss cannot see are not
+            # the first hidden layer is never materialised (rank-one fold, DESIGN.md section 3.1 / profiles/HISTORY.md section 3.1) and levels the loss cannot see are not
             # computed: measured 0.93 GB per trajectory at |E| = 1M where the generic estimate says 1.3 -- 128 trajectories per launch
             # (119 GB at peak) instead of 64, +3.4 % on configs[4] (tools/mb_sweep.py)
             widths = [widths[0]] + widths[2:]

@@ -1,7 +1,7 @@
 """GPU tests of the boundary and the host harness (through the C-ABI): reference-style operands (dense ndarray shifts, a plain
 Bcond_func closure -- TE:240-257, 298-303), the experiment driver train_model() with its -reverse / -regional / -flip_edges
 branches (TE:313-510) against an oracle trainer on the same RNG stream, the two-rank data-parallel gradient step through the HIP
-path, the bf16x3 exact-split kernels against their fp32-MFMA predecessors on wide-dynamic-range data, and flow inputs with
+path, the split-operand MFMA kernels against fp64 on wide-dynamic-range data, and flow inputs with
 repeated entries."""
 import os
 import socket
@@ -292,14 +292,15 @@ def test_two_rank_gradient_step_through_the_hip_path(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# exact-split bf16 kernels on a wide dynamic range
+# split-operand MFMA kernels on a wide dynamic range
 # ------------------------------------------------------------------------------------------------------------------
 
-def test_exact_split_bf16_kernels_hold_fp32_accuracy_on_wide_dynamic_range():
-    """The C=32 / C=16 kernels evaluate fp32 products as six bf16 MFMAs on an exact three-way split.  On slabs whose every row
-    spans 1e-4 .. 1e3 (both signs: hi / mid / lo parts of the split all matter) forward, input gradient and weight gradients must
-    agree with an fp64 evaluation to fp32 accuracy, relative to each output's own sum of |terms| -- a truncated split (plain bf16,
-    or two of the three parts) fails this by orders of magnitude."""
+def test_split_operand_mfma_kernels_hold_fp32_accuracy_on_wide_dynamic_range():
+    """The C=32 / C=16 kernels evaluate fp32 products on the f16 MFMA: both operands split hi + lo under power-of-two row scales,
+    three products, fp32 accumulation (rounds 1-4: six bf16 products of an exact three-way split; the test and its tolerances are
+    unchanged).  On slabs whose every row spans 1e-4 .. 1e3 (both signs: the scales and both parts of the split all matter) forward,
+    input gradient and weight gradients must agree with an fp64 evaluation to fp32 accuracy, relative to each output's own sum of
+    |terms| -- a truncated split (plain f16 / bf16, or an un-scaled f16 split) fails this by orders of magnitude."""
     _need_gpu()
     import scipy.sparse as sp
     from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te

@@ -38,6 +38,7 @@ bunch = any(k.startswith("t") for k in a.which.split(","))          # tfwd / tbw
 if bunch:
     bshifts, bnbr, _ = te.setup_from_complex(sc, "bunch")
 builds = {}
+_lib.AB_OLDER_LIBRARY = True          # a "before" library built from an older revision may lack the newest entry points
 for spec in a.libs.split(","):
     name, path = spec.split("=")
     path = path if os.path.isabs(path) else os.path.join(ROOT, path)
