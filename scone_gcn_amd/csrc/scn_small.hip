@@ -29,7 +29,7 @@
 namespace scn {
 
 constexpr int SM_C = 16;
-constexpr int SM_WAVES_MAX = 12;                // waves per workgroup: 8 (256 registers per lane: up to nine row tiles per wave resident) or, for
+// (SM_WAVES_MAX = 12)                          // waves per workgroup: 8 (256 registers per lane: up to nine row tiles per wave resident) or, for
                                                 // complexes of at most 24 tiles, 12 (170 registers, one or two tiles per wave, three waves per SIMD)
 constexpr int SM_MAX_LAYERS = 6;
 constexpr int SM_ITEMS = 512, SM_MAXD = 64;     // readout item list / neighbourhood width one wave handles (as scn_readout.hip)

@@ -341,6 +341,57 @@ def test_split_operand_mfma_kernels_hold_fp32_accuracy_on_wide_dynamic_range():
             assert (np.abs(dWs[k].cpu().numpy() - refw) / sw).max() <= 1e-4, (C, k)   # fp32 accumulation over S*E*4 = 1e5 terms
 
 
+def test_trajectories_of_different_magnitude_sharing_a_slab():
+    """The scales of the split are per POINT in the forward and per 32-point TILE (8 rows x the 4 trajectories of a slab) in the
+    backward.  Trajectories are independent samples, so their magnitudes may differ inside a tile:
+    (1) three orders of magnitude between the trajectories of a slab (a wide spread for gradients of one batch): forward, input
+        gradient and weight gradients hold the same bars as on uniform data, every output relative to ITS OWN sum of |terms|;
+    (2) nine orders: the forward still does (its scale is the point's own); the input gradient of the smallest trajectory is held
+        relative to the largest trajectory of its tile (2e-10 of that trajectory's sum of |terms| -- the documented bound: f16
+        subnormals under the tile's scale), and the weight gradients, which add all trajectories up, hold their bar unchanged."""
+    _need_gpu()
+    from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(2500)
+    sc = SimplicialComplex(cx)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+    E, C, S = cx.n_edges, 32, 2
+    lo, up = shifts[0].device_csr().astype(np.float64), shifts[1].device_csr().astype(np.float64)
+    rs = np.random.RandomState(23)
+    W32 = [(0.1 * rs.randn(C, C)).astype(np.float32) for _ in range(3)]
+    Wt = [torch.from_numpy(w).cuda() for w in W32]
+    W = [w.astype(np.float64) for w in W32]
+    aux32 = np.tanh(rs.randn(S, E, 4, C)).astype(np.float32)
+    at = torch.from_numpy(aux32).cuda()
+    aux = aux32.astype(np.float64)
+    for spread, dx_bar_own in ((1e-1, 8e-6), (1e-3, None)):
+        mags = np.array([1.0, spread, spread ** 2, spread ** 3])            # 1, 1e-1, 1e-2, 1e-3  /  1, 1e-3, 1e-6, 1e-9
+        x32 = (rs.randn(S, E, 4, C) * mags[None, None, :, None]).astype(np.float32)
+        xt = torch.from_numpy(x32).cuda()
+        fwd = plan.conv.forward([xt], Wt, C, "none").cpu().numpy()
+        dWs = [torch.zeros_like(w) for w in Wt]
+        dx = plan.conv.backward([xt], Wt, at, "tanh", True, dWs).cpu().numpy()
+        x = x32.astype(np.float64)
+        flat = x.transpose(1, 0, 2, 3).reshape(E, -1)
+        sh = lambda m, f: (m @ f).reshape(E, S, 4, C).transpose(1, 0, 2, 3)
+        gk = [x, sh(lo, flat), sh(up, flat)]
+        ga = [np.abs(x), sh(abs(lo), np.abs(flat)), sh(abs(up), np.abs(flat))]
+        ref = sum(a @ w for a, w in zip(gk, W))
+        scale = sum(a @ np.abs(w) for a, w in zip(ga, W))
+        assert (np.abs(fwd - ref) / scale).max() <= 8e-6, spread            # per point: every trajectory to its own magnitude
+        refdx = sum(a @ w.T for a, w in zip(gk, W)) * (1.0 - aux ** 2)
+        sdx = sum(a @ np.abs(w).T for a, w in zip(ga, W))
+        err = np.abs(dx - refdx)
+        if dx_bar_own is not None:
+            assert (err / sdx).max() <= dx_bar_own, spread
+        assert (err / (sdx + 2e-10 * sdx[:, :, :1, :].max(axis=3, keepdims=True))).max() <= 8e-6, spread   # own terms + the tile's largest trajectory
+        for k in range(3):
+            refw = np.einsum("srnc,srnd->cd", aux, gk[k])
+            sw = np.einsum("srnc,srnd->cd", np.abs(aux), ga[k])
+            assert (np.abs(dWs[k].cpu().numpy() - refw) / sw).max() <= 1e-4, (spread, k)
+
+
 def test_bench_lines_of_one_and_two_ranks_agree_on_loss_and_weights():
     """bench.py is self-validating across rank counts (the host draws the batch once, shards by index; STM:256's
     batch axis, STM:313-322's mask semantics): `--gpus 1` and `--gpus 2 --backend gloo` (both ranks on this one GPU, the

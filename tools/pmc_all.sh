@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/r4_pmc.sh <outdir>  -- the rocprofv3 --pmc traffic passes behind bench.py's `roofline.traffic` (FETCH_SIZE, WRITE_SIZE,
+# usage (GPU box): tools/pmc_all.sh <outdir>  -- the rocprofv3 --pmc traffic passes behind bench.py's `roofline.traffic` (FETCH_SIZE, WRITE_SIZE,
 # TCC hit / miss in separate runs: tools/pmc_run.sh), one section per launch shape, merged by tools/pmc_merge.py into <outdir>/pmc_traffic.json
 # and stamped there with the hash of the kernel sources the passes ran on (copy it to profiles/rNN_pmc_traffic.json).
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
-OUT=${1:?usage: tools/r4_pmc.sh <outdir>}
+OUT=${1:?usage: tools/pmc_all.sh <outdir>}
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
 step() {
