@@ -183,7 +183,9 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
                          const int32_t* edge_nodes, /* [n_edges][2] endpoints (tail, head) */
                          const float* bh, const float* d_logp, const float* logp, int32_t act,
                          float* d_logits /* [N][max_deg] out */, float* dz,
-                         int32_t dz_is_zero /* != 0: caller guarantees dz is all zeros (skips the memset of the dense tensor) */,
+                         int32_t dz_is_zero /* 1: caller guarantees dz is all zeros (skips the memset of the dense tensor);
+                                               2: dz may hold anything and the launch zeroes it itself, every trajectory's wave its own
+                                                  column first (small complexes: no fill over the buffer) */,
                          float* d_w_last, void* stream);
 
 /* Writes zeros to exactly the dz entries scn_readout_backward fills for these last_nodes, so a buffer handed in with
@@ -413,6 +415,11 @@ int scn_logits_sum_log_softmax(int32_t n_traj, int32_t max_deg, int32_t n_parts,
  *   loss[0]  += sum_i logp[i] * d_logp[i]    (fp64 accumulator on the device, fixed summation order)
  * n = trajectories x max_deg entries of logp / y / d_logp. */
 int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, void* stream);
+/* The same as the FIRST loss launch of an optimiser step: overwrite != 0 SETS loss[0] instead of adding to it, and zero_buf (or NULL)
+ * -- the flat weight-gradient buffer the backward launches that follow accumulate into, zero_n floats -- is zeroed by the same launch
+ * (on the reference's own problem sizes a step is ~15 launches of 5-15 us: two fill launches are a tenth of it). */
+int scn_masked_ce_begin(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss,
+                        int32_t overwrite, float* zero_buf, int64_t zero_n, void* stream);
 
 /* Fused Adam + ridge step on the flat parameter buffer (jax.experimental.optimizers.adam as driven by
  * STM:300-326; ridge term of STM:54-56):   g' = g * g_scale + 2*weight_decay*w ; m,v EMA ;

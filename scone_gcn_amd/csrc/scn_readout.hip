@@ -183,7 +183,30 @@ __device__ void readout_bwd_serial(int n, int lane, int ns, int n_edges, int c, 
     }
 }
 
-__global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
+// zero dz[s][r][i][0 .. c) for every row r (the whole workgroup; 16-byte stores when the width allows), and wait for the stores:
+// wave 0 writes some of these entries right afterwards (the caller puts a barrier between)
+__device__ __forceinline__ void readout_zero_column(float* __restrict__ dz, int s, int i, int ns, int n_edges, int c, int lane, int nt) {
+    float* base = dz + ((size_t)s * n_edges * ns + i) * c;
+    const size_t estride = (size_t)ns * c;
+    if ((c & 3) == 0) {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const int q = c >> 2;
+        for (int t = lane; t < n_edges * q; t += nt) {
+            const int r = t / q, k = t - r * q;
+            *(f32x4_*)(base + (size_t)r * estride + 4 * k) = f32x4_{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        for (int t = lane; t < n_edges * c; t += nt) {
+            const int r = t / c, k = t - r * c;
+            base[(size_t)r * estride + k] = 0.f;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                   // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __threadfence_block();
+}
+
+constexpr int RO_ZERO_THREADS = 512;           // clear == 2: eight waves zero the column, wave 0 goes on alone
+__global__ __launch_bounds__(RO_ZERO_THREADS) void readout_bwd_kernel(int ns, int n_edges, int c, const float* __restrict__ H,
                                                          const float* __restrict__ w, const int32_t* __restrict__ nbr,
                                                          int max_deg, const int32_t* __restrict__ last_nodes,
                                                          const int32_t* __restrict__ inc_ptr,
@@ -193,7 +216,10 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, in
                                                          const float* __restrict__ d_logp,
                                                          const float* __restrict__ logp, int act,
                                                          float* __restrict__ dz, float* __restrict__ dl_out, int clear) {
-    // clear != 0: write zeros to exactly the dz entries the normal pass writes (scn_readout_clear_dz)
+    // clear == 1: write zeros to exactly the dz entries the normal pass writes (scn_readout_clear_dz)
+    // clear == 2: the workgroup (RO_ZERO_THREADS threads in this form, 64 otherwise) first zeroes its trajectory's whole column of dz
+    //             ([s][all rows][i][:]: nobody else writes there), then wave 0 runs the normal pass alone -- small complexes: no fill
+    //             launch over the gradient buffer, which may hold anything
     __shared__ float dl[RO_MAXD];
     __shared__ int nb[RO_MAXD];
     __shared__ int d_ptr[RO_MAXD + 1], d_start[RO_MAXD];
@@ -202,6 +228,12 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(int ns, int n_edges, in
     __shared__ unsigned char it_d[RO_ITEMS];
     const int n = blockIdx.x, lane = threadIdx.x;
     const int s = n / ns, i = n - s * ns;
+    if (clear == 2) {
+        readout_zero_column(dz, s, i, ns, n_edges, c, threadIdx.x, blockDim.x);
+        __syncthreads();
+        clear = 0;
+        if (threadIdx.x >= 64) return;                 // (a finished wave no longer takes part in the barriers below)
+    }
     const int vlast = last_nodes[n];
     const float g = (!clear && lane < max_deg) ? d_logp[(size_t)n * max_deg + lane] : 0.f;
     const float gs = wave_sum(g);
@@ -529,8 +561,10 @@ __global__ __launch_bounds__(64) void logits_sum_log_softmax_kernel(int max_deg,
 
 __global__ __launch_bounds__(1024) void masked_ce_kernel(int64_t n, const float* __restrict__ logp,
                                                          const float* __restrict__ y, float scale,
-                                                         float* __restrict__ d_logp, double* __restrict__ loss) {
+                                                         float* __restrict__ d_logp, double* __restrict__ loss,
+                                                         int overwrite = 0, float* __restrict__ zero_buf = nullptr, int64_t zero_n = 0) {
     __shared__ double part[1024];
+    for (int64_t t = threadIdx.x; t < zero_n; t += 1024) zero_buf[t] = 0.f;
     double acc = 0.0;
     for (int64_t t = threadIdx.x; t < n; t += 1024) {
         const float d = y[t] * scale;
@@ -543,7 +577,7 @@ __global__ __launch_bounds__(1024) void masked_ce_kernel(int64_t n, const float*
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] += part[0];
+    if (threadIdx.x == 0) loss[0] = overwrite ? part[0] : loss[0] + part[0];
 }
 
 __global__ void adam_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
@@ -597,14 +631,15 @@ int scn_readout_backward(int32_t n_slabs, int32_t ns, int32_t n_edges, int32_t c
     if (max_deg > RO_WIDE) return SCN_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int N = n_slabs * ns;
-    if (!dz_is_zero) SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
+    const bool self_zero = dz_is_zero == 2 && max_deg <= RO_MAXD;          // (the kernel of wide neighbourhoods has no such form)
+    if (!dz_is_zero || (dz_is_zero == 2 && !self_zero)) SCN_HIP_TRY(hipMemsetAsync(dz, 0, sizeof(float) * (size_t)N * n_edges * c, st));
     float* dl = d_logits;
     if (max_deg > RO_MAXD)
         hipLaunchKernelGGL(readout_bwd_wide_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
                            last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
     else
-        hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(64), 0, st, ns, n_edges, c, H, w_last, nbr, max_deg,
-                           last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, 0);
+        hipLaunchKernelGGL(readout_bwd_kernel, dim3(N), dim3(self_zero ? RO_ZERO_THREADS : 64), 0, st, ns, n_edges, c, H, w_last, nbr,
+                           max_deg, last_nodes, inc_ptr, inc_edge, inc_sign, edge_nodes, d_logp, logp, act, dz, dl, self_zero ? 2 : 0);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(readout_dw_kernel, dim3(1), dim3(1024), 0, st, N * max_deg, c, dl, bh, d_w_last);
     SCN_LAUNCH_CHECK();
@@ -731,6 +766,16 @@ int scn_masked_ce(int64_t n, const float* logp, const float* y, float scale, flo
     if (n <= 0) return SCN_ERR_BAD_SHAPE;
     if (!logp || !y || !d_logp || !loss) return SCN_ERR_BAD_ARG;
     hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, logp, y, scale, d_logp, loss);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_masked_ce_begin(int64_t n, const float* logp, const float* y, float scale, float* d_logp, double* loss, int32_t overwrite,
+                        float* zero_buf, int64_t zero_n, void* stream) {
+    if (n <= 0 || zero_n < 0) return SCN_ERR_BAD_SHAPE;
+    if (!logp || !y || !d_logp || !loss || (zero_n > 0 && !zero_buf)) return SCN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(masked_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, logp, y, scale, d_logp, loss, overwrite ? 1 : 0,
+                       zero_buf, zero_n);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

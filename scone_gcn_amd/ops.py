@@ -1077,24 +1077,26 @@ class SconePlan:
         S, E, ns, C = H.shape
         key = (S, E, ns, C)
         pool = self._dz_zero.get(key)
-        dz_top = pool.pop() if pool else torch.zeros_like(H)
+        # small complexes: the launch zeroes the buffer itself, every trajectory's wave its own column (dz_is_zero = 2) -- no fill launch;
+        # large ones: a pooled all-zero buffer whose touched rows are wiped after use (_release_top)
+        small = H.numel() * 4 <= self.SMALL_DZ_BYTES
+        dz_top = pool.pop() if pool else (torch.empty_like(H) if small else torch.zeros_like(H))
         d_logits = torch.empty_like(logp)
         d_logp = d_logp.contiguous()
         check(lib.scn_readout_backward(S, ns, E, C, _dev(H), _dev(weights[-1]), _dev(self.nbr, torch.int32),
                                        self.n_nodes, self.max_deg, _dev(last_dev, torch.int32),
                                        _dev(self.inc_ptr, torch.int32), _dev(self.inc_edge, torch.int32),
                                        _dev(self.inc_sign), _dev(self.edge_nodes, torch.int32), _dev(bh),
-                                       _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz_top), 1,
+                                       _dev(d_logp), _dev(logp), ACT[self.act], _dev(d_logits), _dev(dz_top), 2 if small else 1,
                                        _dev(grads[-1]), _stream()), "scn_readout_backward")
         return dz_top, key
 
-    SMALL_DZ_BYTES = 8 << 20      # below this a plain fill of the buffer is cheaper than walking the readout's rows again (small complexes)
+    SMALL_DZ_BYTES = 8 << 20      # below this the readout's backward zeroes the whole buffer itself instead of keeping it all-zero (small complexes)
 
     def _release_top(self, dz_top, key, last_dev):
         S, E, ns, C = key
         if dz_top.numel() * 4 <= self.SMALL_DZ_BYTES:
-            dz_top.zero_()
-            self._dz_zero.setdefault(key, []).append(dz_top)
+            self._dz_zero.setdefault(key, []).append(dz_top)     # (may hold anything: see _readout_grad)
             return
         check(_lib.load().scn_readout_clear_dz(S, ns, E, C, _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
                                                _dev(last_dev, torch.int32), _dev(self.inc_ptr, torch.int32),

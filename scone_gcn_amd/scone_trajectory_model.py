@@ -386,29 +386,32 @@ class Scone_GCN():
         """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches (fresh: flat_g = ..., i.e. zeroed first).
         Returns that partial loss as a 0-dim device tensor (no host synchronisation inside the step)."""
         lib = _lib.load()
-        if fresh and len(staged) and staged[0][3] is None and type(plan) is ops.SconePlan:
-            # small complex: forward, loss and backward of a micro-batch in one launch; the first one SETS the gradient and the loss
-            part = torch.empty((1,), device=self._flat_w.device, dtype=torch.float64)
-            x, last_dev, yt, _ = staged[0]
-            if plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part, overwrite=True):
-                staged = staged[1:]
-                fresh = False
-            else:
-                part.zero_()
-        else:
-            part = torch.zeros((1,), device=self._flat_w.device, dtype=torch.float64)
-        if fresh:
-            self._flat_g.zero_()
+        # The loss accumulator and (fresh) the gradient buffer are initialised BY the first launch that writes them -- the one-launch
+        # step's overwrite form, or the first loss launch of the layer path (scn_masked_ce_begin) -- not by fill launches of their own:
+        # on the reference's own sizes a step is ~15 launches of 5-15 us each.
+        part = torch.empty((1,), device=self._flat_w.device, dtype=torch.float64)
+        part_set, zero_g = False, bool(fresh)
         for x, last_dev, yt, activity in staged:
-            if activity is None and type(plan) is ops.SconePlan and \
-                    plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part):
-                continue
+            if activity is None and type(plan) is ops.SconePlan:
+                if not part_set and not zero_g:
+                    part.zero_()                                  # (accumulating call whose first micro-batch takes the one-launch step)
+                    part_set = True
+                if plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part, overwrite=not part_set):
+                    part_set, zero_g = True, False
+                    continue
             logp, saved = plan.forward(x, last_dev, self.weights, activity) if activity else plan.forward(x, last_dev, self.weights)
             d_logp = torch.empty_like(logp)
-            _lib.check(lib.scn_masked_ce(logp.numel(), ops._dev(logp), ops._dev(yt), -1.0 / total, ops._dev(d_logp),
-                                         ctypes.c_void_p(part.data_ptr()), ops._stream()), "scn_masked_ce")
+            _lib.check(lib.scn_masked_ce_begin(logp.numel(), ops._dev(logp), ops._dev(yt), -1.0 / total, ops._dev(d_logp),
+                                               ctypes.c_void_p(part.data_ptr()), 0 if part_set else 1,
+                                               ops._dev(self._flat_g) if zero_g else None, self._flat_g.numel() if zero_g else 0,
+                                               ops._stream()), "scn_masked_ce_begin")
+            part_set, zero_g = True, False
             plan.backward(saved, logp, d_logp, last_dev, self.weights, self._grads)
             del saved
+        if not part_set:
+            part.zero_()
+        if zero_g:
+            self._flat_g.zero_()
         return part[0]
 
     def _accumulate_grad(self, plan, inputs, y, idx, total):

@@ -347,8 +347,8 @@ def test_trajectories_of_different_magnitude_sharing_a_slab():
     (1) three orders of magnitude between the trajectories of a slab (a wide spread for gradients of one batch): forward, input
         gradient and weight gradients hold the same bars as on uniform data, every output relative to ITS OWN sum of |terms|;
     (2) nine orders: the forward still does (its scale is the point's own); the input gradient of the smallest trajectory is held
-        relative to the largest trajectory of its tile (2e-10 of that trajectory's sum of |terms| -- the documented bound: f16
-        subnormals under the tile's scale), and the weight gradients, which add all trajectories up, hold their bar unchanged."""
+        relative to the largest trajectory of its tile (1e-11 of that trajectory's sum of |terms|: f16 subnormals under the tile's
+        scale; measured ~1e-12), and the weight gradients, which add all trajectories up, hold their bar unchanged."""
     _need_gpu()
     from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te
     from scone_gcn_amd.complex import SimplicialComplex
@@ -385,7 +385,8 @@ def test_trajectories_of_different_magnitude_sharing_a_slab():
         err = np.abs(dx - refdx)
         if dx_bar_own is not None:
             assert (err / sdx).max() <= dx_bar_own, spread
-        assert (err / (sdx + 2e-10 * sdx[:, :, :1, :].max(axis=3, keepdims=True))).max() <= 8e-6, spread   # own terms + the tile's largest trajectory
+        tile_max = sdx[:, :, :1, :].max(axis=3, keepdims=True)                 # the slab's largest trajectory (index 0) at the same row
+        assert (err / (8e-6 * sdx + 1e-11 * tile_max)).max() <= 1.0, spread    # own terms to fp32 accuracy + 1e-11 of the tile's largest
         for k in range(3):
             refw = np.einsum("srnc,srnd->cd", aux, gk[k])
             sw = np.einsum("srnc,srnd->cd", np.abs(aux), ga[k])
