@@ -390,6 +390,8 @@ def compact_line(line, limit=COMPACT_LIMIT):
     out = {k: line.get(k) for k in head}
     cfg = dict(line.get("config") or {})
     cfg["workload"] = _cut(cfg.get("workload", ""), 220)
+    if cfg.get("arithmetic"):
+        cfg["arithmetic"] = _cut(cfg["arithmetic"], 140)
     if cfg.get("collective"):
         cfg["collective"] = _cut(cfg["collective"], 120)
     out["config"] = cfg
@@ -605,6 +607,8 @@ def main():
                    "edges": E, "nodes": cx.n_nodes, "faces": cx.n_faces, "hidden": C, "global_batch": total,
                    "per_gpu_batch": B, "micro_batch": mb, "parallelism": "dp%d" % world,
                    "collective": collective, "batch_seed": 1030,
+                   "arithmetic": "fp32 tensors and accumulation; dense products on the f16 MFMA as hi+lo splits of both operands under "
+                                 "power-of-two row scales (3 of 4 cross products, dot-product error <= ~3*2^-22*sum|ab|, DESIGN.md 3.2)",
                    "nnz_lower": plan.nnz_lower, "nnz_upper": plan.nnz_upper, "nnz_pattern": plan.nnz_pattern},
         "roofline": roofline, "cpu_baseline": None, "replicas_identical": validation["replicas_identical"],
         "loss": validation["loss"], "validation": validation, "step_model": step_model, "kernels": slim(table), "setup_s": t_setup,

@@ -393,6 +393,47 @@ def test_trajectories_of_different_magnitude_sharing_a_slab():
             assert (np.abs(dWs[k].cpu().numpy() - refw) / sw).max() <= 1e-4, (spread, k)
 
 
+def test_weight_gradient_accumulators_across_slabs_of_very_different_magnitude():
+    """The backward keeps its weight-gradient accumulators in the units of the LARGEST tile a wave has seen so far and rescales them when
+    a larger one arrives.  Slabs are visited in order, so slab magnitudes that rise, fall, vanish (exact-zero
+    slabs: the early-out leaves the running exponent alone) and rise again drive every branch of that bookkeeping; dW (which adds all
+    slabs up) must hold its usual bar, and dx every output's own."""
+    _need_gpu()
+    from scone_gcn_amd import ops, synthetic_data_gen as g, trajectory_experiments as te
+    from scone_gcn_amd.complex import SimplicialComplex
+    cx = g.random_SC_graph(1500)
+    sc = SimplicialComplex(cx)
+    shifts, readout, _ = te.setup_from_complex(sc, "scone")
+    plan = ops.get_scone_plan(shifts[0], shifts[1], readout, "tanh", ops.default_device())
+    E = cx.n_edges
+    lo, up = shifts[0].device_csr().astype(np.float64), shifts[1].device_csr().astype(np.float64)
+    rs = np.random.RandomState(31)
+    for C, act in ((32, "tanh"), (16, "relu")):
+        slab_scale = np.array([1e-6, 1e-3, 0.0, 1.0, 1e4, 0.0, 0.0, 1e-2, 1e-9, 3.0, 1e2])      # rises, vanishes, falls, rises again
+        S = len(slab_scale)
+        x32 = (rs.randn(S, E, 4, C) * slab_scale[:, None, None, None]).astype(np.float32)
+        aux32 = (np.tanh(rs.randn(S, E, 4, C)) if act == "tanh" else np.maximum(rs.randn(S, E, 4, C), 0.0) * 50.0).astype(np.float32)
+        W32 = [(0.2 * rs.randn(C, C)).astype(np.float32) for _ in range(3)]
+        xt, at = torch.from_numpy(x32).cuda(), torch.from_numpy(aux32).cuda()
+        Wt = [torch.from_numpy(w).cuda() for w in W32]
+        dWs = [torch.zeros_like(w) for w in Wt]
+        dx = plan.conv.backward([xt], Wt, at, act, True, dWs).cpu().numpy()
+        x, aux, W = x32.astype(np.float64), aux32.astype(np.float64), [w.astype(np.float64) for w in W32]
+        flat = x.transpose(1, 0, 2, 3).reshape(E, -1)
+        sh = lambda m, f: (m @ f).reshape(E, S, 4, C).transpose(1, 0, 2, 3)
+        gk = [x, sh(lo, flat), sh(up, flat)]
+        ga = [np.abs(x), sh(abs(lo), np.abs(flat)), sh(abs(up), np.abs(flat))]
+        dact = (1.0 - aux ** 2) if act == "tanh" else (aux > 0).astype(np.float64)
+        refdx = sum(a @ w.T for a, w in zip(gk, W)) * dact
+        sdx = sum(a @ np.abs(w).T for a, w in zip(ga, W)) + 1e-300
+        assert (np.abs(dx - refdx) / sdx).max() <= 8e-6, (C, act)
+        assert np.all(dx[slab_scale == 0.0] == 0.0)
+        for k in range(3):
+            refw = np.einsum("srnc,srnd->cd", aux, gk[k])
+            sw = np.einsum("srnc,srnd->cd", np.abs(aux), ga[k])
+            assert (np.abs(dWs[k].cpu().numpy() - refw) / sw).max() <= 1e-4, (C, act, k)
+
+
 def test_bench_lines_of_one_and_two_ranks_agree_on_loss_and_weights():
     """bench.py is self-validating across rank counts (the host draws the batch once, shards by index; STM:256's
     batch axis, STM:313-322's mask semantics): `--gpus 1` and `--gpus 2 --backend gloo` (both ranks on this one GPU, the
