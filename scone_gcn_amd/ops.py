@@ -1289,7 +1289,7 @@ class BunchPlan:
     def _terms_ops(self):
         """The seven shifts as one operator on the concatenated row space, and its transpose (scn_terms_*): the fused layer.
         None when the plan builder cannot hold the complex (SCN_ERR_UNSUPPORTED: a single concatenated row with more than
-        104 distinct sources, e.g. a hub node) -- the per-shift path then carries every layer, forward AND backward."""
+        112 distinct sources, e.g. a hub node) -- the per-shift path then carries every layer, forward AND backward."""
         if self._terms is None and not all(self._live):
             self._terms = False                          # an empty level: the per-shift path (nothing to fuse across three levels)
         if self._terms is None:

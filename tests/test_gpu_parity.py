@@ -484,7 +484,7 @@ def test_spmm_blocks_without_sources():
 
 
 def test_bunch_on_a_complex_with_a_hub_node_falls_back_to_the_per_shift_path():
-    """A node of degree 60: its row of the concatenated Bunch operator has 121 > 104 distinct sources (itself, 60 neighbours, 60
+    """A node of degree 60: its row of the concatenated Bunch operator has 121 > 112 distinct sources (itself, 60 neighbours, 60
     incident edges; the readout kernels take neighbourhoods up to 64 wide, so 60 it is), which the fused-layer plan
     cannot hold (scn_terms_create -> SCN_ERR_UNSUPPORTED).  BunchPlan must then run every layer, forward AND backward, on the
     per-shift SpMM + dense-term path (it used to raise at hidden 32): loss and all 28 weight gradients against the oracle."""
