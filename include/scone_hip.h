@@ -394,7 +394,14 @@ int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, 
  * within 160 KB (|E| <= ~1100); SCN_ERR_UNSUPPORTED otherwise -- the caller then runs the layer-by-layer entry points.
  * Like every launch here it neither allocates nor copies nor synchronises: the handle's entry pack (col, val_lower, val_upper per
  * entry) is built by scn_conv_create* for every operator of this shape and size, so the FIRST call on a fresh handle may already be
- * captured into a HIP graph (tests/test_gpu_small_step.py). */
+ * captured into a HIP graph (tests/test_gpu_small_step.py).
+ * Paired form: when |E| > 384 (at least two blocks of 128 rows) and 2 * n_traj <= the device's CUs, TWO workgroups share a trajectory:
+ * alternating 128-row blocks each, full activations in both LDS, rows handed over through memory after every layer (agent-scope stores,
+ * a flag per phase; the wait is bounded -- a partner that never arrives makes the loss NaN, it cannot hang).  Results are those of the
+ * single form up to the order of the weight-gradient sums (2 N partials instead of N), still bitwise reproducible.  The launch assumes
+ * it has the device to itself for its ~60 us (all workgroups resident together); scn_small_step_pairing(1) turns the form off
+ * process-wide (0: back on, the default).  The workspace size covers both forms. */
+int scn_small_step_pairing(int32_t mode);
 int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, int32_t max_deg, int32_t max_items);
 size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers);
 int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,

@@ -119,6 +119,7 @@ SIGNATURES = {
     "scn_fold1_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "scn_small_step_supported": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32]),
     "scn_small_step_workspace": (c_size_t, [c_i32, c_i32, c_i32]),
+    "scn_small_step_pairing": (ctypes.c_int, [c_i32]),
     "scn_small_step": (ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_f32, c_void_p,
                                       c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_i32,
                                       ctypes.POINTER(c_void_p), c_void_p, c_i32, c_void_p, c_size_t, c_void_p]),

@@ -21,6 +21,7 @@
 // Measured against the layer-by-layer kernels: profiles/r04_small_step_ab.txt; when the trainer takes it: ops.small_step_pays.
 #include "scn_internal.h"
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <utility>
@@ -65,8 +66,12 @@ struct SmallArgs {
     const float* W[3 * SM_MAX_LAYERS + 1];
     float* hs;                                        // [n_layers - 1][N][E][16]  saved activations H_1 .. H_{L-1}
     float* ys;                                        // [N][E][4]                 (x, S_lo x, S_up x, 0): written for non-symmetric shifts only
-    float* partial;                                   // [N][PW]                   per-trajectory weight-gradient partials
-    double* loss_part;                                // [N]
+    float* partial;                                   // [P][PW]                   per-workgroup weight-gradient partials (P = N, paired: 2 N)
+    double* loss_part;                                // [P]
+    // paired form (two workgroups per trajectory, see small_step_kernel): hand-over buffers and flags
+    int32_t n_traj, tag;
+    float* xg;                                        // [n_layers - 1][N][E][16]  H_L, then the dx of layers L .. 3
+    int* flags;                                       // [N][2 SM_MAX_LAYERS][2]   phase p of half h has been stored (= tag)
 };
 
 __host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C + (n_layers - 1) * SM_LAYER_W + SM_C; }
@@ -164,11 +169,11 @@ struct SmOp {
 };
 template <int MAXT, int WAVES>
 __device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent, int E,
-                                           int nt, int wave, int r16, int q) {
+                                           int nt, int t0, int r16, int q) {
     int j0[MAXT];
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-        const int t = wave + WAVES * k, r = 16 * t + r16;
+        const int t = t0 + WAVES * k, r = 16 * t + r16;
         const bool valid = t < nt && r < E;
         j0[k] = valid ? rowptr[r] : 0;
         op.cnt[k] = valid ? rowptr[r + 1] - j0[k] : 0;
@@ -259,9 +264,45 @@ __device__ __forceinline__ void sm_shift_x(const SmOp<MAXT>& op, const int32_t* 
 template <typename F, int... Ks>
 __device__ __forceinline__ void sm_tiles(F&& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
 
-template <int MAXT, int WAVES>
+// Hand-over between the two workgroups of a trajectory (paired form): agent-scope accesses (sc1), which neither hit a stale line of
+// this CU's L1 nor stay behind in it.  Sixteen bytes per instruction (as four relaxed atomics of a dword each -- what the language
+// offers -- the hand-over cost 22 us of a 100 us step instead of ~10), so inline assembly, which the compiler's counters do not see:
+// the stores are waited for explicitly before the barrier that precedes the flag, and a load's result is not touched (nor its
+// register copied: the load is unconditional, its use goes through sm_landed) before the s_waitcnt of sm_landed.
+__device__ __forceinline__ void sm_store_sc1(float* p, f32x4 v) {
+#ifdef SM_AB_PLAIN_STORE
+    *(f32x4*)p = v;
+    return;
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 sm_load_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void sm_landed(f32x4 (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]) : : "memory");
+#pragma unroll
+    for (int k = 1; k < N; ++k) asm volatile("" : "+v"(v[k]) : : "memory");
+}
+#ifndef SM_SPIN_LIMIT
+#define SM_SPIN_LIMIT 400000
+#endif
+
+// PAIRED: two workgroups per trajectory.  The tiles go to them in alternating blocks of WAVES tiles (workgroup `half` takes the tiles
+// wave + WAVES (2 k + half)), each keeps the FULL activation buffers in its LDS and the operator rows of its own tiles in registers,
+// and after every layer (forward: H_l, backward: dx_l) the two hand each other their rows through memory: the rows are stored with
+// agent scope, a flag per (phase, half) is raised once the workgroup's stores have been acknowledged, the partner waits for it and
+// loads the rows into its own LDS.  The readout (a few hundred items) is done by both.  The two workgroups of a pair are
+// blockIdx b and b + 8 -- the same XCD, one L2 -- and the host takes this form only when all workgroups of the launch are resident
+// together (2 N <= CUs; a workgroup's LDS leaves room for one per CU), so the wait below always ends; it is bounded all the same
+// (SM_SPIN_LIMIT polls, ~0.3 s): a partner that never arrives turns the trajectory's loss into NaN instead of hanging the device.
+template <int MAXT, int WAVES, bool PAIRED>
 __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     constexpr int SM_THREADS = 64 * WAVES, SM_WAVES = WAVES;
+    constexpr int TS = PAIRED ? 2 * WAVES : WAVES;              // tile stride of a wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.n_edges, L = a.n_layers, act = a.act;
     const SmallLds lay = small_lds(E);
@@ -281,12 +322,56 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     float* dwf_red = bh + 64 * SM_C;         // [waves][48]
     float* xs = (float*)(smem + lay.off_x);  // [epad] the input flow of this trajectory
     float2* ysl = (float2*)(smem + lay.off_y);  // [epad] (S_lo x, S_up x), when there is room (lay.y_lds)
-    const int n = blockIdx.x, s = n / a.ns, i = n - s * a.ns;
-    const int N = gridDim.x;
+    const int half = PAIRED ? (blockIdx.x >> 3) & 1 : 0;
+    const int n = PAIRED ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x;
+    if (n >= a.n_traj) return;                                  // (paired: the grid is padded to whole groups of sixteen)
+    const int s = n / a.ns, i = n - s * a.ns;
+    const int N = a.n_traj;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
+    const int t0 = wave + (PAIRED ? WAVES * half : 0);          // first tile of this wave
     const int PW = small_pw(L);
-    float* my_partial = a.partial + (size_t)n * PW;
+    const int my_p = PAIRED ? 2 * n + half : n;
+    float* my_partial = a.partial + (size_t)my_p * PW;
+    int* const fail = d_ptr + 79;                               // (the list of slots ends at d_ptr[max_deg <= 64])
+    int* const flags_n = PAIRED ? a.flags + (size_t)n * (4 * SM_MAX_LAYERS) : nullptr;
+    float* const xg_n = PAIRED ? a.xg + (size_t)n * E * SM_C : nullptr;
+    if (PAIRED && tid == 0) *fail = 0;
+    // phase p of this half is in memory: called by every thread after a barrier that followed the wave's s_waitcnt vmcnt(0)
+    auto post = [&](int phase) {
+        if (PAIRED && tid == 0) __hip_atomic_store(flags_n + 2 * phase + half, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // wait for the partner's phase p and bring its rows (blocks 2 k + 1 - half of 16 WAVES rows) from `src` into `out`
+    auto collect = [&](float* out, const float* src, int phase) {
+        if constexpr (PAIRED) {
+#ifdef SM_AB_NO_COLLECT
+            return;
+#endif
+            if (tid == 0) {
+                const int* f = flags_n + 2 * phase + (1 - half);
+                int spins = 0;
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
+                    if (++spins > SM_SPIN_LIMIT) { *fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+            f32x4 v[MAXT];
+            const int qq = tid & 3;
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k) {
+                const int r = (2 * k + 1 - half) * (16 * WAVES) + (tid >> 2);
+                v[k] = sm_load_sc1(src + (size_t)(r < E ? r : 0) * SM_C + 4 * qq);
+            }
+            sm_landed(v);
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k) {
+                const int r = (2 * k + 1 - half) * (16 * WAVES) + (tid >> 2);
+                if (r < epad) *(f32x4*)(out + sm_at(r, qq)) = r < E ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        }
+    };
     SM_STAMP(0);
 #ifdef SCN_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[14] = clock64();
@@ -305,7 +390,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         ro_y = a.y[(size_t)n * a.max_deg + lane];
     }
     SmOp<MAXT> op;
-    sm_load_op<MAXT, WAVES>(op, a.rowptr, a.ent, E, nt, wave, r16, q);
+    sm_load_op<MAXT, TS>(op, a.rowptr, a.ent, E, nt, t0, r16, q);
 
     // ---------------- layer 1 (one input channel): y = (x, S_lo x, S_up x), H_1 = act(y . W_1)
     for (int e = tid; e < epad; e += SM_THREADS) xs[e] = e < E ? a.x[((size_t)s * E + e) * a.ns + i] : 0.f;
@@ -324,7 +409,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         for (int j = 0; j < 4; ++j) { w0[j] = Wl[4 * q + j]; w1[j] = Wl[SM_C + 4 * q + j]; w2[j] = Wl[2 * SM_C + 4 * q + j]; }
         auto tile = [&](auto kc) {
             constexpr int K = decltype(kc)::value;
-            int t = wave + SM_WAVES * K;
+            int t = t0 + TS * K;
             asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
             if (t >= nt) return;
             const int r = 16 * t + r16;
@@ -338,13 +423,17 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             *(f32x4*)(out + sm_at(r, q)) = o;
             if (lay.y_lds && q == 0) ysl[r] = make_float2(lo, up);
             if (valid) {
-                *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * q) = o;
+                if constexpr (PAIRED) sm_store_sc1(hs_n + (size_t)r * SM_C + 4 * q, o);
+                else *(f32x4*)(hs_n + (size_t)r * SM_C + 4 * q) = o;
                 if (!lay.y_lds && !a.same_t && q == 0) ysn[r] = make_float4(x0, lo, up, 0.f);
             }
         };
         sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
     }
+    if constexpr (PAIRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    post(0);
+    collect(lds, hs_n, 0);
     if (wave == 0 && ro_v >= 0) {
         ro_start = a.inc_ptr[ro_v];
         ro_cnt = a.inc_ptr[ro_v + 1] - ro_start;
@@ -365,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             for (int u = 0; u < 4; ++u) wa[g][u] = Wl[g * 256 + (4 * q + u) * SM_C + r16];
         auto tile = [&](auto kc) {
             constexpr int K = decltype(kc)::value;
-            int t = wave + SM_WAVES * K;
+            int t = t0 + TS * K;
             asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
             if (t >= nt) return;
             const int r = 16 * t + r16;
@@ -388,12 +477,19 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             if (!valid) o = f32x4{0.f, 0.f, 0.f, 0.f};
             SM_CYC(3, K == 1 && li == 1);
             *(f32x4*)(out + sm_at(r, q)) = o;
-            if (valid && li < L - 1) *(f32x4*)(hs_n + li * hs_layer + (size_t)r * SM_C + 4 * q) = o;
+            if constexpr (PAIRED) {
+                if (valid) sm_store_sc1((li < L - 1 ? hs_n + li * hs_layer : xg_n) + (size_t)r * SM_C + 4 * q, o);
+            } else {
+                if (valid && li < L - 1) *(f32x4*)(hs_n + li * hs_layer + (size_t)r * SM_C + 4 * q) = o;
+            }
             SM_CYC(4, K == 1 && li == 1);
             SM_CYC(5, K == 2 && li == 1);
         };
         sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
+        if constexpr (PAIRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        post(li);
+        collect(out, li < L - 1 ? hs_n + li * hs_layer : xg_n, li);
         if (li == 1 && wave == 0) {
 #pragma unroll
             for (int j = 0; j < SM_RO_PRE; ++j)
@@ -461,7 +557,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         double lpart = live ? (double)lp * (double)gy : 0.0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lpart += __shfl_xor(lpart, o, 64);
-        if (lane == 0) a.loss_part[n] = overflow ? (double)NAN : lpart;
+        if (lane == 0) a.loss_part[my_p] = overflow ? (double)NAN : (half == 0 ? lpart : 0.0);    // (paired: both halves do the readout)
         const float gs = sm_wave_sum(gy);
         if (live) dls[lane] = gy - expf(lp) * gs;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
@@ -470,7 +566,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         for (int d = g; d < a.max_deg; d += 4) dwl = fmaf(dls[d], bh[d * SM_C + cc], dwl);
         dwl += __shfl_xor(dwl, 16, 64);
         dwl += __shfl_xor(dwl, 32, 64);
-        if (lane < SM_C) my_partial[PW - SM_C + lane] = dwl;
+        if (lane < SM_C) my_partial[PW - SM_C + lane] = half == 0 ? dwl : 0.f;
     }
     __syncthreads();
     SM_STAMP(9);
@@ -494,7 +590,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     }
     // (the saved activations hs / ys are read back from here on: every store to them has been acknowledged by the L2 at a barrier since --
     //  __syncthreads() waits for the wave's vector-memory counter -- and none of their lines has been loaded into this CU's L1 before)
-    if (!a.same_t) sm_load_op<MAXT, WAVES>(op, a.rowptr_t, a.ent_t, E, nt, wave, r16, q);      // the backward gathers through the transpose
+    if (!a.same_t) sm_load_op<MAXT, TS>(op, a.rowptr_t, a.ent_t, E, nt, t0, r16, q);      // the backward gathers through the transpose
     const float4* ent_b = a.same_t ? a.ent : a.ent_t;
     const int32_t* rowptr_b = a.same_t ? a.rowptr : a.rowptr_t;
     __syncthreads();
@@ -534,7 +630,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             for (int j = 0; j < 4; ++j) dwf[g][j] = 0.f;
         auto tile = [&](auto kc) {
             constexpr int K = decltype(kc)::value;
-            int t = wave + SM_WAVES * K;
+            int t = t0 + TS * K;
             asm volatile("" : "+s"(t));                          // (per-tile addresses are recomputed, not kept in registers across the layers)
             if (t >= nt) return;
             const int r = 16 * t + r16;
@@ -564,6 +660,8 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             if (li > 1) {
                 asm volatile("" ::: "memory");                   // (the reads of this tile's aux rows above stay above)
                 *(f32x4*)(out + sm_at(r, q)) = dx;
+                if constexpr (PAIRED)
+                    if (valid) sm_store_sc1(xg_n + (size_t)(L - li) * hs_layer + (size_t)r * SM_C + 4 * q, dx);
             } else {                                             // dW_1[g][c] += y[row][g] * dx[row][c]
                 float y0, y1, y2;
                 if (lay.y_lds) {
@@ -598,7 +696,9 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             }
         };
         sm_tiles(tile, std::make_integer_sequence<int, MAXT>{});
+        if constexpr (PAIRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // every wave is done with `in`
+        if (li > 1) post(2 * L - 1 - li);                        // (the partner's wait overlaps the reduction below)
         float* red = red_overlay ? lds + in_o : (float*)(smem + lay.off_red);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
@@ -628,10 +728,12 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             for (int w = 0; w < SM_WAVES; ++w) sum += dwf_red[w * 48 + tid];
             my_partial[tid] = sum;
         }
+        if (li > 1) collect(out, xg_n + (size_t)(L - li) * hs_layer, 2 * L - 1 - li);
         __syncthreads();
         SM_STAMP(10 + (L - li));
         const int tmp = in_o; in_o = out_o; out_o = tmp;
     }
+    if (PAIRED && tid == 0 && *fail) a.loss_part[my_p] = (double)NAN;      // the partner never arrived
 #ifdef SCN_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[15] = clock64();
 #endif
@@ -646,9 +748,12 @@ struct SmallReduce {
     const float* partial;
     const double* loss_part;
     double* loss;
+    int* flags;                                       // paired form: the hand-over flags go back to zero for the next launch / replay
+    int32_t n_flags;
 };
 __global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
     __shared__ float part[256];
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < a.n_flags; f += gridDim.x * 256) a.flags[f] = 0;
     const int oo = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int o = blockIdx.x * 16 + oo;
     float acc = 0.f;
@@ -678,10 +783,27 @@ static bool small_shape(const scn_conv_s* c) {
     return c && c->n_groups == 1 && c->g[0].identity == 1 && c->g[0].n_vals == 2 && c->g[0].n_cols == c->n_rows;
 }
 
-template <int T, int WV>
+template <int T, int WV, bool PAIRED = false>
 static int small_raise_lds(size_t bytes) {
-    SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    SCN_HIP_TRY(hipFuncSetAttribute((const void*)small_step_kernel<T, WV, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return SCN_OK;
+}
+
+// The paired form: blocks of eight tiles alternate between the two workgroups, the first takes ceil(blocks / 2) of them.
+static inline int small_blocks(int n_edges) { return (((n_edges + 15) >> 4) + 7) / 8; }
+static std::atomic<int> g_small_pairing{0};          // 0: when it applies, 1: never (scn_small_step_pairing)
+static std::atomic<int> g_small_tag{0};
+static int small_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+        else cus = 0;
+    }
+    return cus;
+}
+static bool small_paired(int n_edges, int n_traj) {
+    return g_small_pairing.load() == 0 && small_waves(n_edges) == 8 && small_blocks(n_edges) >= 2 && 2 * n_traj <= small_cus();
 }
 
 // Called by scn_conv_create* (scn_conv.hip) on every new handle: an operator scn_small_step can serve gets its entry pack
@@ -715,6 +837,16 @@ int small_prepare(scn_conv_s* c) {
         else if (tiles_per_wave <= 8) st = small_raise_lds<8, 8>(lay.total);
         else st = small_raise_lds<SM_MAXT, 8>(lay.total);
         if (st != SCN_OK) return st;
+        if (waves == 8 && small_blocks(c->n_rows) >= 2) {
+            switch ((small_blocks(c->n_rows) + 1) / 2) {
+                case 1: st = small_raise_lds<1, 8, true>(lay.total); break;
+                case 2: st = small_raise_lds<2, 8, true>(lay.total); break;
+                case 3: st = small_raise_lds<3, 8, true>(lay.total); break;
+                case 4: st = small_raise_lds<4, 8, true>(lay.total); break;
+                default: st = small_raise_lds<5, 8, true>(lay.total); break;
+            }
+            if (st != SCN_OK) return st;
+        }
     }
     return SCN_OK;
 }
@@ -746,8 +878,15 @@ size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layer
     if (n_edges <= 0 || n_traj <= 0 || n_layers < 2 || n_layers > SM_MAX_LAYERS) return 0;
     const size_t hs = (size_t)(n_layers - 1) * n_traj * n_edges * SM_C * 4;
     const size_t ys = (size_t)n_traj * n_edges * 16;
-    const size_t part = ((size_t)n_traj * small_pw(n_layers) * 4 + 15) / 16 * 16;
-    return hs + ys + part + (size_t)n_traj * 8 + 256;
+    const size_t part = ((size_t)2 * n_traj * small_pw(n_layers) * 4 + 15) / 16 * 16;     // (sized for the paired form: 2 N partials,
+    const size_t flags = (size_t)n_traj * 4 * SM_MAX_LAYERS * 4;                          //  hand-over buffers of the size of hs, flags)
+    return hs + ys + part + (size_t)2 * n_traj * 8 + hs + flags + 256;
+}
+
+int scn_small_step_pairing(int32_t mode) {
+    if (mode < 0 || mode > 1) return SCN_ERR_BAD_ARG;
+    g_small_pairing.store(mode);
+    return SCN_OK;
 }
 
 int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
@@ -782,21 +921,44 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     ws += (size_t)N * E * 16;
     a.partial = (float*)ws;
     const int pw = small_pw(n_layers);
-    ws += ((size_t)N * pw * 4 + 15) / 16 * 16;
+    ws += ((size_t)2 * N * pw * 4 + 15) / 16 * 16;
     a.loss_part = (double*)ws;
+    ws += (size_t)2 * N * 8;
+    a.xg = (float*)ws;
+    ws += (size_t)(n_layers - 1) * N * E * SM_C * 4;
+    a.flags = (int*)ws;
+    a.n_traj = N;
+    const bool paired = small_paired(E, N);
+    if (paired) {
+        // A fresh word per launch, never zero (the flags' resting value: small_reduce_kernel puts them back, so a graph replay -- same
+        // tag -- starts from zeros as well).  A workspace used for the first time holds arbitrary words; one of them equal to this
+        // launch's tag in the very cell a workgroup polls is a 2^-32 event per cell.
+        a.tag = (int32_t)(((uint32_t)(g_small_tag.fetch_add(1) + 1) * 2654435761u) | 1u);
+    }
     const SmallLds lay = small_lds(E);
     hipStream_t s = (hipStream_t)stream;
     const int waves = small_waves(E);
     const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;
-#define SCN_LAUNCH_SMALL(T, WV) hipLaunchKernelGGL((small_step_kernel<T, WV>), dim3(N), dim3(64 * WV), lay.total, s, a)
-    if (waves == 12) { if (tiles_per_wave <= 1) SCN_LAUNCH_SMALL(1, 12); else SCN_LAUNCH_SMALL(2, 12); }
+#define SCN_LAUNCH_SMALL(T, WV) hipLaunchKernelGGL((small_step_kernel<T, WV, false>), dim3(N), dim3(64 * WV), lay.total, s, a)
+#define SCN_LAUNCH_PAIRED(T) hipLaunchKernelGGL((small_step_kernel<T, 8, true>), dim3(16 * ((N + 7) / 8)), dim3(512), lay.total, s, a)
+    if (paired) {
+        switch ((small_blocks(E) + 1) / 2) {
+            case 1: SCN_LAUNCH_PAIRED(1); break;
+            case 2: SCN_LAUNCH_PAIRED(2); break;
+            case 3: SCN_LAUNCH_PAIRED(3); break;
+            case 4: SCN_LAUNCH_PAIRED(4); break;
+            default: SCN_LAUNCH_PAIRED(5); break;
+        }
+    } else if (waves == 12) { if (tiles_per_wave <= 1) SCN_LAUNCH_SMALL(1, 12); else SCN_LAUNCH_SMALL(2, 12); }
     else if (tiles_per_wave <= 3) SCN_LAUNCH_SMALL(3, 8);
     else if (tiles_per_wave <= 6) SCN_LAUNCH_SMALL(6, 8);
     else if (tiles_per_wave <= 8) SCN_LAUNCH_SMALL(8, 8);
     else SCN_LAUNCH_SMALL(SM_MAXT, 8);
     SCN_LAUNCH_CHECK();
     SmallReduce r{};
-    r.n_traj = N; r.pw = pw; r.n_w = 3 * n_layers + 1; r.overwrite = overwrite ? 1 : 0;
+    r.n_traj = paired ? 2 * N : N; r.pw = pw;
+    r.flags = paired ? a.flags : nullptr;
+    r.n_flags = paired ? N * 4 * SM_MAX_LAYERS : 0; r.n_w = 3 * n_layers + 1; r.overwrite = overwrite ? 1 : 0;
     int off = 0;
     for (int k = 0; k < r.n_w; ++k) {
         r.off[k] = off;

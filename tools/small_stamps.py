@@ -21,6 +21,8 @@ net.use_graph = False
 net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, np.ones(N, int), model_type="scone")
 staged = net.stage(inputs, y, np.arange(N))
 lib = _lib.load()
+if os.environ.get("SCN_SMALL_PAIRING") == "0":
+    lib.scn_small_step_pairing(1)
 lib.scn_debug_small_stamps.restype = ctypes.c_int
 out = (ctypes.c_ulonglong * 16)()
 names = {0: "requests issued; x, W1 -> LDS", 1: "layer 1: y = (x, S_lo x, S_up x), H1", 3: "layer 2", 4: "layer 3 (or: readout, if 2 layers)",

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scone_gcn_amd import synthetic_data_gen as g, trajectory_experiments as te, scone_trajectory_model as stm
 from scone_gcn_amd.complex import SimplicialComplex
 eager = "eager" in sys.argv
+if os.environ.get("SCN_SMALL_PAIRING") == "0":                  # A/B: one workgroup per trajectory even where two would be taken
+    from scone_gcn_amd import _lib
+    _lib.load().scn_small_step_pairing(1)
 steps = int(next((a for a in sys.argv[1:] if a.isdigit()), 300))
 pts = int(os.environ.get("SCN_POINTS", "400"))                  # 400 points: |E| = 1001 (TE:86-90); 130: |E| ~ 320 (the drifter complex's size)
 cx = g.random_SC_graph(pts); sc = SimplicialComplex(cx)
