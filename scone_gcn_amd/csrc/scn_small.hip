@@ -392,6 +392,26 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     SmOp<MAXT> op;
     sm_load_op<MAXT, TS>(op, a.rowptr, a.ent, E, nt, t0, r16, q);
 
+    // A layer's three weight matrices are requested one layer AHEAD into registers and written to LDS when their layer starts: read
+    // where they are needed they were a round trip to the L2 between two barriers, ~2 us of every layer in both directions.
+    constexpr int WPT = (SM_LAYER_W + SM_THREADS - 1) / SM_THREADS;
+    float wpre[WPT];
+    auto request_w = [&](int li) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int o = tid + j * SM_THREADS;
+            wpre[j] = o < SM_LAYER_W ? a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)] : 0.f;
+        }
+    };
+    auto place_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int o = tid + j * SM_THREADS;
+            if (o < SM_LAYER_W) Wl[o] = wpre[j];
+        }
+    };
+    request_w(1);
+
     // ---------------- layer 1 (one input channel): y = (x, S_lo x, S_up x), H_1 = act(y . W_1)
     for (int e = tid; e < epad; e += SM_THREADS) xs[e] = e < E ? a.x[((size_t)s * E + e) * a.ns + i] : 0.f;
     if (tid < 3 * SM_C) Wl[tid] = a.W[tid / SM_C][tid % SM_C];
@@ -445,8 +465,9 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     for (int li = 1; li < L; ++li) {
         const float* in = lds + in_o;
         float* out = lds + out_o;
-        for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) Wl[o] = a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)];
+        place_w();
         __syncthreads();
+        if (li + 1 < L) request_w(li + 1);                       // (the last layer's stay in LDS for the backward's first)
         float wa[3][4];                                          // A[m = c_out = r16][k = (s, q)] = W_g[4 q + s][r16]
 #pragma unroll
         for (int g = 0; g < 3; ++g)
@@ -611,12 +632,14 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             const float* aux = hs_n + (size_t)(li - 1) * hs_layer;
             for (int idx = tid; idx < epad * 4; idx += SM_THREADS) {
                 const int r = idx >> 2, qq = idx & 3;
+                if (PAIRED && ((idx / SM_THREADS) & 1) != half) continue;       // (the tiles read aux at their own rows only)
                 const f32x4 v = r < E ? *(const f32x4*)(aux + (size_t)r * SM_C + 4 * qq) : f32x4{0.f, 0.f, 0.f, 0.f};
                 *(f32x4*)(out + sm_at(r, qq)) = v;
             }
         }
-        for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) Wl[o] = a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)];
+        if (li < L - 1) place_w();
         __syncthreads();
+        if (li > 1) request_w(li - 1);
         f32x4 wb[3];                                             // A[m = c = r16][k = (s, q)] = W_g[r16][4 q + s]
 #pragma unroll
         for (int g = 0; g < 3; ++g) wb[g] = *(const f32x4*)(Wl + g * 256 + r16 * SM_C + 4 * q);
@@ -839,7 +862,6 @@ int small_prepare(scn_conv_s* c) {
         if (st != SCN_OK) return st;
         if (waves == 8 && small_blocks(c->n_rows) >= 2) {
             switch ((small_blocks(c->n_rows) + 1) / 2) {
-                case 1: st = small_raise_lds<1, 8, true>(lay.total); break;
                 case 2: st = small_raise_lds<2, 8, true>(lay.total); break;
                 case 3: st = small_raise_lds<3, 8, true>(lay.total); break;
                 case 4: st = small_raise_lds<4, 8, true>(lay.total); break;
@@ -943,7 +965,6 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
 #define SCN_LAUNCH_PAIRED(T) hipLaunchKernelGGL((small_step_kernel<T, 8, true>), dim3(16 * ((N + 7) / 8)), dim3(512), lay.total, s, a)
     if (paired) {
         switch ((small_blocks(E) + 1) / 2) {
-            case 1: SCN_LAUNCH_PAIRED(1); break;
             case 2: SCN_LAUNCH_PAIRED(2); break;
             case 3: SCN_LAUNCH_PAIRED(3); break;
             case 4: SCN_LAUNCH_PAIRED(4); break;

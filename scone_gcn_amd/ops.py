@@ -86,6 +86,15 @@ FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first i
 #   |E| = 1001:  100 trajectories 0.119 / 0.120   128: 0.121 / 0.122   160: 0.123 / 0.144   256: 0.134 / 0.150   512: 0.242 / 0.193
 # One workgroup's chain does not shorten with the batch, so the launch costs (rounds of 256 workgroups) x (chain of this |E|); the layer
 # kernels grow with the work.  At |E| = 1001 the chain is eight row tiles per wave and layer: worth it for a full round, not beyond.
+# Round 5: above 384 edges and up to CUs / 2 trajectories the library gives every trajectory TWO workgroups (half the row tiles each,
+# rows handed over through memory after every layer; include/scone_hip.h), paired / one workgroup each / layer by layer, ms
+# (tools/small_pair_ab.sh, profiles/r05_small_pair_ab.txt; the layer kernels themselves are round 5's):
+#   |E| =  498:   64 trajectories 0.056 / 0.067 / 0.088   128: 0.060 / 0.069 / 0.099
+#   |E| =  639:   64: 0.070 / 0.080 / 0.095   100: 0.072 / 0.082 / 0.102   128: 0.074 / 0.082 / 0.105
+#   |E| =  822:   64: 0.073 / 0.093 / 0.097   100: 0.078 / 0.094 / 0.105   128: 0.079 / 0.095 / 0.106
+#   |E| = 1001:   32: 0.083 / 0.113 / 0.089    64: 0.086 / 0.114 / 0.101   100: 0.088 / 0.119 / 0.109   128: 0.090 / 0.119 / 0.111
+#   |E| = 1106:   64: 0.089 / 0.120 / 0.099   100: 0.094 / 0.122 / 0.121   128: 0.097 / 0.125 / 0.126
+# -- wherever that form applies it is the fastest of the three.
 SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
 SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 960     # up to here for any batch of one round
 
@@ -105,6 +114,8 @@ def small_step_pays(n_edges, n_traj, n_cus=256):
     """The size rule for the one-launch step (see the table above); n_traj counts the padded trajectories = workgroups, n_cus the
     device's compute units (callers pass device_cus(); the table was measured on 256)."""
     rounds = -(-n_traj // n_cus)
+    if n_edges > 384 and 2 * n_traj <= n_cus:          # two workgroups per trajectory (the library's own condition, small_paired())
+        return True
     if n_edges <= min(384, SMALL_STEP_MAX_EDGES):
         return rounds <= 4
     if n_edges <= min(768, SMALL_STEP_MAX_EDGES):

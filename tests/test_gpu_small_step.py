@@ -133,6 +133,31 @@ def test_small_step_is_bitwise_reproducible_and_flip_invariant(cfg1, sc1):
     assert np.abs(np.abs(a[1]) - np.abs(c[1])).max() <= 2e-6 * np.abs(a[1]).max() + 1e-7     # W_0, W_1, W_2 gradients keep their values
 
 
+def test_two_workgroups_per_trajectory_agree_with_one(cfg1, sc1):
+    """scn_small_step's paired form (|E| = 1001, 100 trajectories: the reference's own batch, TE:86-90; 200 workgroups that hand each
+    other their rows after every layer) against the same launch with one workgroup per trajectory (scn_small_step_pairing(1)):
+    the same loss and gradients up to the order of the weight-gradient sums, and bitwise the same from launch to launch."""
+    from scone_gcn_amd import _lib
+    lib = _lib.load()
+    sel = np.arange(60, 160)
+    net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 16)] * 3, 8.0, True)
+    try:
+        assert lib.scn_small_step_pairing(1) == 0
+        one = _step(net, inputs, cfg1["targets"], sel)
+        assert lib.scn_small_step_pairing(0) == 0
+        two = [_step(net, inputs, cfg1["targets"], sel) for _ in range(3)]
+    finally:
+        lib.scn_small_step_pairing(0)
+    assert any(k.startswith("small_step") for k in one[2]) and any(k.startswith("small_step") for k in two[0][2])
+    for t in two[1:]:
+        assert t[0] == two[0][0] and np.array_equal(t[1], two[0][1])
+    gmax = np.abs(one[1]).max()
+    assert gmax > 1e-4 and np.isfinite(two[0][0])
+    assert abs(two[0][0] - one[0]) <= 2e-6 * max(1.0, abs(one[0])) and np.abs(two[0][1] - one[1]).max() <= 2e-6 * max(gmax, 1.0)
+    assert not np.array_equal(two[0][1], one[1])                     # (2 N partials instead of N: the knob did switch the form)
+    assert lib.scn_small_step_pairing(2) != 0
+
+
 def test_small_step_inside_the_replayed_graph(cfg1, sc1):
     """The graph-replayed optimiser step (Scone_GCN._graph_accumulate) captures the one-launch step: three Adam steps replayed equal
     three eager ones bit for bit, and the weights move."""
@@ -233,10 +258,13 @@ def test_small_step_refuses_what_it_does_not_serve(cfg1, sc1):
     assert not any(k.startswith("small_step") for k in table) and any(k.startswith("conv_fwd") for k in table)
 
 
-@pytest.mark.parametrize("n_pts,n_traj", [(130, 37), (250, 12), (80, 5), (440, 9)])
+@pytest.mark.parametrize("n_pts,n_traj", [(130, 37), (250, 12), (80, 5), (440, 9), (200, 11), (330, 100), (250, 160)])
 def test_small_step_on_other_complex_sizes_against_the_layer_by_layer_kernels(n_pts, n_traj):
     """The kernel's instances by row tiles per wave: |E| ~ 320 (three, the drifter complex's size), ~ 620 (six), ~ 190 (two for
-    some waves, one for others) and ~ 1100 (nine: the largest complex whose two activation buffers fit the LDS)."""
+    some waves, one for others) and ~ 1100 (nine: the largest complex whose two activation buffers fit the LDS).  Above 384 edges
+    and up to 128 trajectories two workgroups share a trajectory (alternating blocks of eight row tiles: two blocks each at
+    |E| ~ 500, three at ~ 620, four at ~ 820 with a whole batch of 100 -- 200 workgroups resident together --, five at ~ 1100);
+    160 trajectories at |E| ~ 620 are past that form's limit and run one workgroup each."""
     from scone_gcn_amd import ops
     from scone_gcn_amd import scone_trajectory_model as stm
     from scone_gcn_amd import synthetic_data_gen as g

@@ -529,7 +529,11 @@ def test_one_launch_step_is_taken_where_it_was_measured_to_pay():
     assert pays(319, 160) and pays(319, 512) and pays(319, 1000) and not pays(319, 2000)
     assert pays(639, 100) and pays(639, 512) and not pays(639, 1000)
     assert pays(822, 100) and pays(926, 100) and not pays(926, 300)
-    assert not pays(1001, 100) and pays(1001, 128) and pays(1001, 200) and pays(1001, 256) and not pays(1001, 512)
+    assert pays(1001, 200) and pays(1001, 256) and not pays(1001, 512)
+    # two workgroups per trajectory (|E| > 384, 2 x trajectories <= CUs): the fastest form at every size it was measured on
+    # (profiles/r05_small_pair_ab.txt), the reference's own batch (|E| = 1001, 100 trajectories) included
+    assert pays(1001, 100) and pays(1001, 128) and pays(1001, 32) and pays(1106, 100) and pays(498, 64)
+    assert pays(1001, 160)                                # (past that form: the one-workgroup rule of round 4)
     keep = ops.SMALL_STEP_MAX_EDGES
     try:
         ops.SMALL_STEP_MAX_EDGES = 1 << 30               # SCN_SMALL_STEP=force
