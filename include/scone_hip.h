@@ -397,7 +397,7 @@ int scn_plan_gather_stats(int32_t n, const int32_t* rowptr, const int32_t* col, 
  * captured into a HIP graph (tests/test_gpu_small_step.py).
  * Paired form: when |E| > 384 (at least two blocks of 128 rows) and 2 * n_traj <= the device's CUs, TWO workgroups share a trajectory:
  * alternating 128-row blocks each, full activations in both LDS, rows handed over through memory after every layer (agent-scope stores,
- * a flag per phase; the wait is bounded -- a partner that never arrives makes the loss NaN, it cannot hang).  Results are those of the
+ * a flag per phase; the wait is bounded -- a partner that never arrives makes the loss and the weight gradients NaN, it cannot hang).  Results are those of the
  * single form up to the order of the weight-gradient sums (2 N partials instead of N), still bitwise reproducible.  The launch assumes
  * it has the device to itself for its ~60 us (all workgroups resident together); scn_small_step_pairing(1) turns the form off
  * process-wide (0: back on, the default).  The workspace size covers both forms. */

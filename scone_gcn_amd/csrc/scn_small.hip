@@ -339,6 +339,9 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     if (PAIRED && tid == 0) *fail = 0;
     // phase p of this half is in memory: called by every thread after a barrier that followed the wave's s_waitcnt vmcnt(0)
     auto post = [&](int phase) {
+#ifdef SM_AB_DROP_POST                                           // (diagnostic build, tools/small_pair_timeout.sh: a partner that never arrives)
+        if (half == 1 && phase == 1) return;
+#endif
         if (PAIRED && tid == 0) __hip_atomic_store(flags_n + 2 * phase + half, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // wait for the partner's phase p and bring its rows (blocks 2 k + 1 - half of 16 WAVES rows) from `src` into `out`
@@ -756,7 +759,10 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         SM_STAMP(10 + (L - li));
         const int tmp = in_o; in_o = out_o; out_o = tmp;
     }
-    if (PAIRED && tid == 0 && *fail) a.loss_part[my_p] = (double)NAN;      // the partner never arrived
+    if (PAIRED && *fail) {                                       // the partner never arrived (every hand-over is barriers back): neither the
+        if (tid == 0) a.loss_part[my_p] = (double)NAN;           // loss nor the gradients of this launch may pass for results
+        for (int o = tid; o < PW; o += SM_THREADS) my_partial[o] = NAN;
+    }
 #ifdef SCN_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_small_stamps[15] = clock64();
 #endif
