@@ -148,6 +148,10 @@ struct scn_conv_s {
     scn::BlockPlan plan;
     scn::TermsPlan terms;
     void* small_pack = nullptr;         // (col, val0, val1, 0) per entry for scn_small_step, built by scn_conv_create* (small_prepare; owned through plan.allocs)
+    void* small_ell = nullptr;          // the first twelve entries of every row at a fixed stride, columns as LDS offsets: [n_rows][12] float4 (same owner)
+    void* small_ovf = nullptr;          // the entries past the twelfth of each row in the same form, small_n_ovf of them,
+    int32_t* small_ovf_ptr = nullptr;   // [n_rows + 1] a row's range among them
+    int32_t small_n_ovf = 0;
     std::vector<uint8_t> block_start;   // optional layout hint: 1 where a block of the plan must start (see scn_plan_refine_order)
 };
 

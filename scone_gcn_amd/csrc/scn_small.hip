@@ -58,6 +58,10 @@ struct SmallArgs {
     int32_t n_edges, ns, n_layers, act, max_deg, same_t;
     const int32_t* rowptr;   const float4* ent;      // operator rows: (col, val_lower, val_upper, 0) per entry
     const int32_t* rowptr_t; const float4* ent_t;    // its transpose (the same arrays for symmetric shifts: same_t)
+    const float4* ell; const float4* ell_t;           // [E][12] the rows' first twelve entries at a fixed stride, columns as LDS offsets
+    const float4* ovf;   const int32_t* ovf_ptr;     // the entries past a row's twelfth in the same form, a row's range among them ([E + 1]);
+    const float4* ovf_t; const int32_t* ovf_ptr_t;   // n_ovf / n_ovf_t entries in all
+    int32_t n_ovf, n_ovf_t;
     const float* x;                                   // [S][E][ns]
     const int32_t* last_nodes;                        // [S * ns]
     const float* y;                                   // [S * ns][max_deg]
@@ -80,10 +84,11 @@ __host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C +
 struct SmallLds {
     int epad;
     bool y_lds;                                       // (S_lo x, S_up x) of every row stay in LDS for the first layer's weight gradient
-    size_t off_w, off_misc, off_x, off_red, off_y, total;
+    bool ovf_lds;                                     // the operator's entries past a row's twelfth stay in LDS (else: read from memory)
+    size_t off_w, off_misc, off_x, off_red, off_y, off_ovf, total;
 };
 __host__ __device__ static inline int small_waves(int n_edges) { return ((n_edges + 15) >> 4) <= 24 ? 12 : 8; }
-__host__ __device__ static inline SmallLds small_lds(int n_edges) {
+__host__ __device__ static inline SmallLds small_lds(int n_edges, int n_ovf) {
     const int waves = small_waves(n_edges);
     SmallLds L;
     L.epad = (n_edges + 15) & ~15;
@@ -96,6 +101,11 @@ __host__ __device__ static inline SmallLds small_lds(int n_edges) {
     L.off_red = L.off_x + (size_t)L.epad * 4;
     const size_t red = (size_t)waves * SM_LAYER_W * 4;
     L.total = L.off_red + (buf >= red ? 0 : red);            // big buffers: the reduction overlays the dead input buffer
+    const size_t ovf = ((size_t)n_ovf * 12 + 15) & ~(size_t)15;    // three floats per entry
+    L.off_ovf = L.total;
+    L.ovf_lds = n_ovf > 0 && waves == 8 && L.total + ovf <= 160 * 1024;    // (every layer needs it, both directions: before the first layer's y
+                                                             //  below; the twelve-wave kernels of |E| <= 384 measured no gain: 0.053 / 0.054 ms)
+    if (L.ovf_lds) L.total += ovf;
     L.off_y = L.total;
     L.y_lds = L.total + (size_t)L.epad * 8 <= 160 * 1024;    // (the largest complexes recompute them from the flow instead)
     if (L.y_lds) L.total += (size_t)L.epad * 8;
@@ -166,30 +176,30 @@ template <int MAXT>
 struct SmOp {
     float enc[MAXT][3], v0[MAXT][3], v1[MAXT][3];     // enc: the column as a ready byte offset into an activation buffer (sm_enc; >> 6 = the column)
     int cnt[MAXT], cmax[MAXT];                        // entries of the row, most entries of any row of the tile (wave-uniform)
+    int ovs[MAXT];                                    // where the row's entries past the twelfth start in the overflow list
 };
-template <int MAXT, int WAVES>
-__device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent, int E,
-                                           int nt, int t0, int r16, int q) {
-    int j0[MAXT];
+template <int MAXT, int WAVES, bool OVF>
+__device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ell,
+                                           const int32_t* __restrict__ ovf_ptr, int E, int nt, int t0, int r16, int q) {
+    // The entries come from the fixed-stride copy (small_prepare): their addresses do not wait for the row pointers -- one round trip
+    // to the L2 at the head of the kernel instead of two.  Entries past a row's end are stored as column 0 with zero values, so the
+    // gather needs no per-entry predicate (straight-line code: all LDS operations of a tile issue back to back).
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
         const int t = t0 + WAVES * k, r = 16 * t + r16;
         const bool valid = t < nt && r < E;
-        j0[k] = valid ? rowptr[r] : 0;
-        op.cnt[k] = valid ? rowptr[r + 1] - j0[k] : 0;
+        op.cnt[k] = valid ? rowptr[r + 1] - rowptr[r] : 0;
+        if constexpr (OVF) op.ovs[k] = (ovf_ptr && valid) ? ovf_ptr[r] : 0;      // (null: the list is not in LDS, the tails are read from memory)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float4 e = ell[(size_t)(valid ? r : 0) * SM_CH + q + 4 * s];
+            op.enc[k][s] = valid ? e.x : 0.f;
+            op.v0[k][s] = valid ? e.y : 0.f;
+            op.v1[k][s] = valid ? e.z : 0.f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int u = q + 4 * s;
-            const bool have = u < op.cnt[k];                     // entries past the row's end: column 0 with zero values, so that the
-            const float4 e = ent[have ? j0[k] + u : 0];          // gather needs no per-entry predicate (straight-line code: all LDS
-            const int c = have ? __float_as_int(e.x) : 0;        // operations of a tile issue back to back)
-            op.enc[k][s] = __int_as_float((int)sm_enc(c));
-            op.v0[k][s] = have ? e.y : 0.f;
-            op.v1[k][s] = have ? e.z : 0.f;
-        }
         int m = op.cnt[k] < SM_CH ? op.cnt[k] : SM_CH;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
@@ -197,9 +207,9 @@ __device__ __forceinline__ void sm_load_op(SmOp<MAXT>& op, const int32_t* __rest
     }
 }
 // lo += sum_u val_lower[u] * H[col_u][quad q], up likewise, over the entries of tile k's row
-template <int MAXT, int K>
+template <int MAXT, int K, bool OVF>
 __device__ __forceinline__ void sm_gather(const SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent,
-                                          const float* in, int r, int r16, int q, f32x4& lo, f32x4& up) {
+                                          const float* ovf, const float* in, int r, int r16, int q, f32x4& lo, f32x4& up) {
     // Two halves of six entries, each: all eighteen exchanges, then all six reads, then the FMAs -- two LDS latencies per half instead of
     // two per entry (a wave's tile is a latency chain: 2400 of its 4900 cycles were this gather while it went entry by entry).
 #ifndef SM_GB
@@ -227,20 +237,34 @@ __device__ __forceinline__ void sm_gather(const SmOp<MAXT>& op, const int32_t* _
             }
         }
     }
-    if (op.cnt[K] > SM_CH) {                                    // rows longer than the register copy (the Ebli pair L1, L1^2)
-        const int j0 = rowptr[r];
-        for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
-            const float4 e = ent[j];
-            const f32x4 d = *(const f32x4*)(in + sm_at(__float_as_int(e.x), q));
-            lo += e.y * d;
-            up += e.z * d;
+    // Rows longer than the register copy: a quarter of the rows of the reference's own complexes (|E| = 1001: mean 11.2 entries, 236
+    // rows of 13 .. 20; the Ebli pair L1, L1^2 has many more) and nearly every tile has one.  Their tails come from the overflow list
+    // in LDS.  Read from memory -- the first form, kept for lists the LDS has no room for -- they are loads in the middle of the
+    // tile's chain whose s_waitcnt also waits for every OLDER store of the wave (one counter): harmless while those are plain stores,
+    // but in the paired form the previous tile's agent-scope stores are acknowledged by the memory side, ~2 us later.
+    if (op.cnt[K] > SM_CH) {
+        if (OVF && ovf) {
+            const float* e = ovf + 3 * op.ovs[K];
+            for (int j = SM_CH; j < op.cnt[K]; ++j, e += 3) {
+                const f32x4 d = *(const f32x4*)((const char*)in + ((uint32_t)__float_as_int(e[0]) ^ (uint32_t)(16 * q)));
+                lo += e[1] * d;
+                up += e[2] * d;
+            }
+        } else {
+            const int j0 = rowptr[r];
+            for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
+                const float4 e = ent[j];
+                const f32x4 d = *(const f32x4*)(in + sm_at(__float_as_int(e.x), q));
+                lo += e.y * d;
+                up += e.z * d;
+            }
         }
     }
 }
 // (S_lo x)[row], (S_up x)[row] of tile k's row from the staged flow: each lane its own entries, the row's four lanes add up
-template <int MAXT, int K>
+template <int MAXT, int K, bool OVF>
 __device__ __forceinline__ void sm_shift_x(const SmOp<MAXT>& op, const int32_t* __restrict__ rowptr, const float4* __restrict__ ent,
-                                           const float* xs, int r, int q, float& lo, float& up) {
+                                           const float* ovf, const float* xs, int r, int q, float& lo, float& up) {
     lo = 0.f; up = 0.f;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -249,12 +273,21 @@ __device__ __forceinline__ void sm_shift_x(const SmOp<MAXT>& op, const int32_t* 
         up = fmaf(op.v1[K][s], xv, up);
     }
     if (q == 0 && op.cnt[K] > SM_CH) {
-        const int j0 = rowptr[r];
-        for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
-            const float4 e = ent[j];
-            const float xv = xs[__float_as_int(e.x)];
-            lo = fmaf(e.y, xv, lo);
-            up = fmaf(e.z, xv, up);
+        if (OVF && ovf) {
+            const float* e = ovf + 3 * op.ovs[K];
+            for (int j = SM_CH; j < op.cnt[K]; ++j, e += 3) {
+                const float xv = xs[__float_as_int(e[0]) >> 6];
+                lo = fmaf(e[1], xv, lo);
+                up = fmaf(e[2], xv, up);
+            }
+        } else {
+            const int j0 = rowptr[r];
+            for (int j = j0 + SM_CH; j < j0 + op.cnt[K]; ++j) {
+                const float4 e = ent[j];
+                const float xv = xs[__float_as_int(e.x)];
+                lo = fmaf(e.y, xv, lo);
+                up = fmaf(e.z, xv, up);
+            }
         }
     }
     lo += __shfl_xor(lo, 16, 64); lo += __shfl_xor(lo, 32, 64);
@@ -305,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     constexpr int TS = PAIRED ? 2 * WAVES : WAVES;              // tile stride of a wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.n_edges, L = a.n_layers, act = a.act;
-    const SmallLds lay = small_lds(E);
+    const SmallLds lay = small_lds(E, a.n_ovf > a.n_ovf_t ? a.n_ovf : a.n_ovf_t);
     const int epad = lay.epad, nt = epad >> 4;
     float* const lds = (float*)smem;                            // (buffers are addressed as lds + offset: the compiler keeps LDS instructions)
     const int bufsz = epad * SM_C;                              // floats per activation buffer: A at 0, B at bufsz
@@ -322,6 +355,11 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     float* dwf_red = bh + 64 * SM_C;         // [waves][48]
     float* xs = (float*)(smem + lay.off_x);  // [epad] the input flow of this trajectory
     float2* ysl = (float2*)(smem + lay.off_y);  // [epad] (S_lo x, S_up x), when there is room (lay.y_lds)
+    float* const ovf_l = (float*)(smem + lay.off_ovf);          // [n_ovf][3] the operator's overflow list, when there is room (lay.ovf_lds)
+    // (the twelve-wave kernels of |E| <= 384 have no register to spare for it and measured no gain, small_lds; the nine-tile instance
+    //  of |E| > 1024 has neither the registers nor the LDS)
+    constexpr bool OVF = WAVES == 8 && (PAIRED || MAXT <= 8);
+    const float* const ovf = OVF && lay.ovf_lds ? ovf_l : nullptr;
     const int half = PAIRED ? (blockIdx.x >> 3) & 1 : 0;
     const int n = PAIRED ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x;
     if (n >= a.n_traj) return;                                  // (paired: the grid is padded to whole groups of sixteen)
@@ -355,7 +393,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
                 int spins = 0;
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
                     if (++spins > SM_SPIN_LIMIT) { *fail = 1; break; }
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             __syncthreads();
@@ -393,24 +431,39 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
         ro_y = a.y[(size_t)n * a.max_deg + lane];
     }
     SmOp<MAXT> op;
-    sm_load_op<MAXT, TS>(op, a.rowptr, a.ent, E, nt, t0, r16, q);
+    sm_load_op<MAXT, TS, OVF>(op, a.rowptr, a.ell, lay.ovf_lds ? a.ovf_ptr : nullptr, E, nt, t0, r16, q);
+    if (lay.ovf_lds)
+        for (int j = tid; j < a.n_ovf; j += SM_THREADS) {
+            const float4 e = a.ovf[j];
+            ovf_l[3 * j] = e.x; ovf_l[3 * j + 1] = e.y; ovf_l[3 * j + 2] = e.z;
+        }
 
     // A layer's three weight matrices are requested one layer AHEAD into registers and written to LDS when their layer starts: read
     // where they are needed they were a round trip to the L2 between two barriers, ~2 us of every layer in both directions.
+    // (The twelve-wave kernels of |E| <= 384 run at 168 of their 170 registers: they read the weights where they need them.)
+    constexpr bool W_AHEAD = WAVES == 8 && (PAIRED || MAXT <= 8);     // (nor has the nine-tile instance: profiles/r05_small_pair_ab.txt)
     constexpr int WPT = (SM_LAYER_W + SM_THREADS - 1) / SM_THREADS;
     float wpre[WPT];
+    int w_layer = 1;
     auto request_w = [&](int li) {
+        w_layer = li;
+        if constexpr (W_AHEAD) {
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int o = tid + j * SM_THREADS;
-            wpre[j] = o < SM_LAYER_W ? a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)] : 0.f;
+            for (int j = 0; j < WPT; ++j) {
+                const int o = tid + j * SM_THREADS;
+                wpre[j] = o < SM_LAYER_W ? a.W[3 * li + o / (SM_C * SM_C)][o % (SM_C * SM_C)] : 0.f;
+            }
         }
     };
     auto place_w = [&]() {
+        if constexpr (W_AHEAD) {
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int o = tid + j * SM_THREADS;
-            if (o < SM_LAYER_W) Wl[o] = wpre[j];
+            for (int j = 0; j < WPT; ++j) {
+                const int o = tid + j * SM_THREADS;
+                if (o < SM_LAYER_W) Wl[o] = wpre[j];
+            }
+        } else {
+            for (int o = tid; o < SM_LAYER_W; o += SM_THREADS) Wl[o] = a.W[3 * w_layer + o / (SM_C * SM_C)][o % (SM_C * SM_C)];
         }
     };
     request_w(1);
@@ -438,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             const int r = 16 * t + r16;
             const bool valid = r < E;
             float lo, up;
-            sm_shift_x<MAXT, K>(op, a.rowptr, a.ent, xs, r, q, lo, up);
+            sm_shift_x<MAXT, K, OVF>(op, a.rowptr, a.ent, ovf, xs, r, q, lo, up);
             const float x0 = xs[r];
             f32x4 o;
             o = sm_act4(act, x0 * w0 + lo * w1 + up * w2);
@@ -485,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             const bool valid = r < E;
             SM_CYC(0, K == 1 && li == 1);
             f32x4 zs = *(const f32x4*)(in + sm_at(r, q)), zl = {0.f, 0.f, 0.f, 0.f}, zu = zl;     // (rows past the end hold zeros)
-            sm_gather<MAXT, K>(op, a.rowptr, a.ent, in, r, r16, q, zl, zu);
+            sm_gather<MAXT, K, OVF>(op, a.rowptr, a.ent, ovf, in, r, r16, q, zl, zu);
             SM_CYC(1, K == 1 && li == 1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = acc, acu = acc;   // three independent chains (a dependent MFMA waits ~40 cycles)
 #pragma unroll
@@ -614,7 +667,14 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     }
     // (the saved activations hs / ys are read back from here on: every store to them has been acknowledged by the L2 at a barrier since --
     //  __syncthreads() waits for the wave's vector-memory counter -- and none of their lines has been loaded into this CU's L1 before)
-    if (!a.same_t) sm_load_op<MAXT, TS>(op, a.rowptr_t, a.ent_t, E, nt, t0, r16, q);      // the backward gathers through the transpose
+    if (!a.same_t) {                                            // the backward gathers through the transpose (the forward's last use of the
+        sm_load_op<MAXT, TS, OVF>(op, a.rowptr_t, a.ell_t, lay.ovf_lds ? a.ovf_ptr_t : nullptr, E, nt, t0, r16, q);          // overflow list is barriers back)
+        if (lay.ovf_lds)
+            for (int j = tid; j < a.n_ovf_t; j += SM_THREADS) {
+                const float4 e = a.ovf_t[j];
+                ovf_l[3 * j] = e.x; ovf_l[3 * j + 1] = e.y; ovf_l[3 * j + 2] = e.z;
+            }
+    }
     const float4* ent_b = a.same_t ? a.ent : a.ent_t;
     const int32_t* rowptr_b = a.same_t ? a.rowptr : a.rowptr_t;
     __syncthreads();
@@ -671,7 +731,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
             f32x4 G[3];
             G[0] = *(const f32x4*)(in + sm_at(r, q));
             G[1] = G[2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            sm_gather<MAXT, K>(op, rowptr_b, ent_b, in, r, r16, q, G[1], G[2]);
+            sm_gather<MAXT, K, OVF>(op, rowptr_b, ent_b, ovf, in, r, r16, q, G[1], G[2]);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = acc, acu = acc;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -694,7 +754,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
                     const float2 lu = ysl[r];
                     y0 = xs[r]; y1 = lu.x; y2 = lu.y;
                 } else if (a.same_t) {
-                    sm_shift_x<MAXT, K>(op, rowptr_b, ent_b, xs, r, q, y1, y2);
+                    sm_shift_x<MAXT, K, OVF>(op, rowptr_b, ent_b, ovf, xs, r, q, y1, y2);
                     y0 = xs[r];
                 } else {
                     const float4 yv = valid ? ysn[r] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -841,7 +901,7 @@ static bool small_paired(int n_edges, int n_traj) {
 // on a fresh handle can be captured into a HIP graph).  Other operators: nothing to do.
 int small_prepare(scn_conv_s* c) {
     if (!small_shape(c) || c->n_rows > 16 * 8 * SM_MAXT) return SCN_OK;
-    const SmallLds lay = small_lds(c->n_rows);
+    const SmallLds lay = small_lds(c->n_rows, 0);
     if (lay.total > 160 * 1024) return SCN_OK;
     const Group& G = c->g[0];
     std::vector<float4> h((size_t)std::max<int64_t>(G.nnz, 1));
@@ -856,22 +916,60 @@ int small_prepare(scn_conv_s* c) {
     c->plan.allocs.push_back(d);
     SCN_HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->small_pack = d;
-    if (lay.total > 64 * 1024) {
+    std::vector<float4> ell((size_t)c->n_rows * SM_CH, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int32_t r = 0; r < c->n_rows; ++r)
+        for (int64_t j = G.h_rowptr[r]; j < G.h_rowptr[r + 1] && j < (int64_t)G.h_rowptr[r] + SM_CH; ++j) {
+            const int32_t col = G.h_col[j];
+            const uint32_t enc = (uint32_t)(col * SM_C + 4 * ((col >> 2) & 3)) * 4u;      // = sm_enc(col)
+            float ef;
+            std::memcpy(&ef, &enc, 4);
+            ell[(size_t)r * SM_CH + (j - G.h_rowptr[r])] = make_float4(ef, G.h_val0[j], G.h_val1[j], 0.f);
+        }
+    void* de = nullptr;
+    SCN_HIP_TRY(hipMalloc(&de, std::max<size_t>(ell.size(), 1) * sizeof(float4)));
+    c->plan.allocs.push_back(de);
+    if (!ell.empty()) SCN_HIP_TRY(hipMemcpy(de, ell.data(), ell.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->small_ell = de;
+    std::vector<int32_t> op_ptr((size_t)c->n_rows + 1, 0);
+    std::vector<float4> ov;
+    for (int32_t r = 0; r < c->n_rows; ++r) {
+        op_ptr[r] = (int32_t)ov.size();
+        for (int64_t j = (int64_t)G.h_rowptr[r] + SM_CH; j < G.h_rowptr[r + 1]; ++j) {
+            const int32_t col = G.h_col[j];
+            const uint32_t enc = (uint32_t)(col * SM_C + 4 * ((col >> 2) & 3)) * 4u;
+            float ef;
+            std::memcpy(&ef, &enc, 4);
+            ov.push_back(make_float4(ef, G.h_val0[j], G.h_val1[j], 0.f));
+        }
+    }
+    op_ptr[c->n_rows] = (int32_t)ov.size();
+    c->small_n_ovf = (int32_t)ov.size();
+    void* dp = nullptr;
+    SCN_HIP_TRY(hipMalloc(&dp, op_ptr.size() * 4));
+    c->plan.allocs.push_back(dp);
+    SCN_HIP_TRY(hipMemcpy(dp, op_ptr.data(), op_ptr.size() * 4, hipMemcpyHostToDevice));
+    c->small_ovf_ptr = (int32_t*)dp;
+    void* dv = nullptr;
+    SCN_HIP_TRY(hipMalloc(&dv, std::max<size_t>(ov.size(), 1) * sizeof(float4)));
+    c->plan.allocs.push_back(dv);
+    if (!ov.empty()) SCN_HIP_TRY(hipMemcpy(dv, ov.data(), ov.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->small_ovf = dv;
+    {                                                           // (the kernels' LDS limit: whatever a launch's layout comes to, overflow list included)
         const int waves = small_waves(c->n_rows);
         const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;
         int st;
-        if (waves == 12) st = tiles_per_wave <= 1 ? small_raise_lds<1, 12>(lay.total) : small_raise_lds<2, 12>(lay.total);
-        else if (tiles_per_wave <= 3) st = small_raise_lds<3, 8>(lay.total);
-        else if (tiles_per_wave <= 6) st = small_raise_lds<6, 8>(lay.total);
-        else if (tiles_per_wave <= 8) st = small_raise_lds<8, 8>(lay.total);
-        else st = small_raise_lds<SM_MAXT, 8>(lay.total);
+        if (waves == 12) st = tiles_per_wave <= 1 ? small_raise_lds<1, 12>((size_t)160 * 1024) : small_raise_lds<2, 12>((size_t)160 * 1024);
+        else if (tiles_per_wave <= 3) st = small_raise_lds<3, 8>((size_t)160 * 1024);
+        else if (tiles_per_wave <= 6) st = small_raise_lds<6, 8>((size_t)160 * 1024);
+        else if (tiles_per_wave <= 8) st = small_raise_lds<8, 8>((size_t)160 * 1024);
+        else st = small_raise_lds<SM_MAXT, 8>((size_t)160 * 1024);
         if (st != SCN_OK) return st;
         if (waves == 8 && small_blocks(c->n_rows) >= 2) {
             switch ((small_blocks(c->n_rows) + 1) / 2) {
-                case 2: st = small_raise_lds<2, 8, true>(lay.total); break;
-                case 3: st = small_raise_lds<3, 8, true>(lay.total); break;
-                case 4: st = small_raise_lds<4, 8, true>(lay.total); break;
-                default: st = small_raise_lds<5, 8, true>(lay.total); break;
+                case 2: st = small_raise_lds<2, 8, true>((size_t)160 * 1024); break;
+                case 3: st = small_raise_lds<3, 8, true>((size_t)160 * 1024); break;
+                case 4: st = small_raise_lds<4, 8, true>((size_t)160 * 1024); break;
+                default: st = small_raise_lds<5, 8, true>((size_t)160 * 1024); break;
             }
             if (st != SCN_OK) return st;
         }
@@ -899,7 +997,7 @@ int scn_small_step_supported(scn_conv_t conv, int32_t n_layers, int32_t hidden, 
     if (n_layers < 2 || n_layers > SM_MAX_LAYERS || hidden != SM_C) return 0;
     if (max_deg <= 0 || max_deg > SM_MAXD || max_items > SM_ITEMS) return 0;
     if (conv->n_rows > 16 * 8 * SM_MAXT || !conv->small_pack) return 0;     // the pack is built by scn_conv_create* (small_prepare)
-    return small_lds(conv->n_rows).total <= 160 * 1024 ? 1 : 0;
+    return small_lds(conv->n_rows, 0).total <= 160 * 1024 ? 1 : 0;
 }
 
 size_t scn_small_step_workspace(int32_t n_edges, int32_t n_traj, int32_t n_layers) {
@@ -937,6 +1035,10 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     if (!conv_t->small_pack) return SCN_ERR_UNSUPPORTED;
     a.ent = (const float4*)conv->small_pack;
     a.ent_t = (const float4*)conv_t->small_pack;
+    a.ell = (const float4*)conv->small_ell;
+    a.ell_t = (const float4*)conv_t->small_ell;
+    a.ovf = (const float4*)conv->small_ovf; a.ovf_ptr = conv->small_ovf_ptr; a.n_ovf = conv->small_n_ovf;
+    a.ovf_t = (const float4*)conv_t->small_ovf; a.ovf_ptr_t = conv_t->small_ovf_ptr; a.n_ovf_t = conv_t->small_n_ovf;
     a.rowptr = conv->g[0].d_rowptr;
     a.rowptr_t = conv_t->g[0].d_rowptr;
     a.x = x; a.last_nodes = last_nodes; a.y = y; a.scale = scale;
@@ -963,7 +1065,7 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
         // launch's tag in the very cell a workgroup polls is a 2^-32 event per cell.
         a.tag = (int32_t)(((uint32_t)(g_small_tag.fetch_add(1) + 1) * 2654435761u) | 1u);
     }
-    const SmallLds lay = small_lds(E);
+    const SmallLds lay = small_lds(E, std::max(a.n_ovf, a.n_ovf_t));
     hipStream_t s = (hipStream_t)stream;
     const int waves = small_waves(E);
     const int tiles_per_wave = ((lay.epad >> 4) + waves - 1) / waves;

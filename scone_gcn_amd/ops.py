@@ -89,11 +89,11 @@ FUSE_FIRST = True      # False: separate scn_conv_backward + scn_conv_dw_first i
 # Round 5: above 384 edges and up to CUs / 2 trajectories the library gives every trajectory TWO workgroups (half the row tiles each,
 # rows handed over through memory after every layer; include/scone_hip.h), paired / one workgroup each / layer by layer, ms
 # (tools/small_pair_ab.sh, profiles/r05_small_pair_ab.txt; the layer kernels themselves are round 5's):
-#   |E| =  498:   64 trajectories 0.056 / 0.067 / 0.088   128: 0.060 / 0.069 / 0.099
-#   |E| =  639:   64: 0.070 / 0.080 / 0.095   100: 0.072 / 0.082 / 0.102   128: 0.074 / 0.082 / 0.105
-#   |E| =  822:   64: 0.073 / 0.093 / 0.097   100: 0.078 / 0.094 / 0.105   128: 0.079 / 0.095 / 0.106
-#   |E| = 1001:   32: 0.083 / 0.113 / 0.089    64: 0.086 / 0.114 / 0.101   100: 0.088 / 0.119 / 0.109   128: 0.090 / 0.119 / 0.111
-#   |E| = 1106:   64: 0.089 / 0.120 / 0.099   100: 0.094 / 0.122 / 0.121   128: 0.097 / 0.125 / 0.126
+#   |E| =  498:   64 trajectories 0.054 / 0.066 / 0.089   128: 0.057 / 0.068 / 0.100
+#   |E| =  639:   64: 0.065 / 0.078 / 0.094   100: 0.067 / 0.079 / 0.101   128: 0.069 / 0.079 / 0.103
+#   |E| =  822:   64: 0.069 / 0.091 / 0.097   100: 0.072 / 0.093 / 0.105   128: 0.073 / 0.093 / 0.107
+#   |E| = 1001:   32: 0.076 / 0.106 / 0.089    64: 0.079 / 0.107 / 0.102   100: 0.081 / 0.110 / 0.109   128: 0.083 / 0.111 / 0.111
+#   |E| = 1106:   64: 0.088 / 0.118 / 0.099   100: 0.093 / 0.119 / 0.121   128: 0.094 / 0.121 / 0.125
 # -- wherever that form applies it is the fastest of the three.
 SMALL_STEP = os.environ.get("SCN_SMALL_STEP", "1") != "0"
 SMALL_STEP_MAX_EDGES = (1 << 30) if os.environ.get("SCN_SMALL_STEP") == "force" else 960     # up to here for any batch of one round
