@@ -7,7 +7,8 @@
 // trajectory's activation tensor (|E| x 16 floats) fits the LDS of a CU.  So: one workgroup per trajectory runs every layer,
 // the readout, the cross-entropy and the whole backward on LDS-resident activations, with workgroup barriers between layers and
 // no halo, no staging and no inter-workgroup dependency; the per-trajectory weight-gradient partials are then summed in a fixed
-// order by a second, tiny launch.
+// order by a second, tiny launch.  Where half the device would idle (|E| > 384 and 2 x trajectories <= CUs) a trajectory gets TWO
+// workgroups that hand each other their rows after every layer (PAIRED, see small_step_kernel).
 //
 //   lane (r = lane & 15, q = lane >> 4) of a wave owns row 16 t + r of tile t and the channel quad 4 q .. 4 q + 3: it gathers
 //   sum_j S[row][col_j] * H[col_j][quad] with 16-byte LDS reads, and that register layout IS the B operand of
@@ -18,7 +19,8 @@
 //   The operator's rows stay in REGISTERS for the whole launch (SmOp below): a lane serves the same rows in every layer.
 //
 // Served: hidden width 16, one input channel, 2 .. 6 layers, |E| small enough for two activation buffers in 160 KB of LDS (~1100).
-// Measured against the layer-by-layer kernels: profiles/r04_small_step_ab.txt; when the trainer takes it: ops.small_step_pays.
+// Measured against the layer-by-layer kernels: profiles/r04_small_step_ab.txt, profiles/r05_small_pair_ab.txt; when the trainer
+// takes it: ops.small_step_pays.
 #include "scn_internal.h"
 
 #include <atomic>
@@ -36,7 +38,7 @@ constexpr int SM_MAX_LAYERS = 6;
 constexpr int SM_ITEMS = 512, SM_MAXD = 64;     // readout item list / neighbourhood width one wave handles (as scn_readout.hip)
 constexpr int SM_LAYER_W = 3 * SM_C * SM_C;     // 768 weights per layer
 constexpr int SM_CH = 12;                       // operator entries of a row kept in registers (three per lane of the row's four); longer rows
-                                                // read their tail from memory in every pass
+                                                // take their tail from the overflow list in LDS (from memory where it has no room)
 constexpr int SM_RO_PRE = 6;                    // readout items per neighbour slot requested at kernel start
 constexpr int SM_MAXT = 9;                      // 16-row tiles per wave at most: |E| <= 16 * 8 * 9 = 1152
 
