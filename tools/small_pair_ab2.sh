@@ -1,3 +1,5 @@
+# usage (on the GPU box): tools/small_pair_ab2.sh -- what the hand-over of the paired one-launch step costs: the step with the collect skipped
+# (-DSM_AB_NO_COLLECT, wrong results), with plain instead of agent-scope stores (-DSM_AB_PLAIN_STORE), and with both, at |E| = 1001 / 100 trajectories.
 set -euo pipefail
 export TMPDIR=/tmp
 O=gpurun_out/pair3; mkdir -p $O
