@@ -409,6 +409,17 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
                    int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
                    const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same step when the batch is ONE micro-batch on ONE rank, ending with the optimiser step: dW[k] = gradient, loss[0] = loss
+ * (the overwrite form), and the launch that sums the gradient applies scn_adam_step's update (g_scale = 1) to the weights, which must
+ * be ONE flat buffer w_flat with W[k] pointing into it in list order (m_flat / v_flat alike; SCN_ERR_BAD_ARG otherwise).  The step index
+ * comes from step_dev[0] as for scn_adam_step_dev (step_dev[1] is scratch: the index in flight); step_dev[0] is advanced.  Bitwise the
+ * weights of scn_small_step(overwrite) followed by scn_adam_step_dev. */
+int scn_small_step_adam(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                        const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                        int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                        const float* const* W, int32_t act, float* const* dW, double* loss, void* workspace, size_t workspace_bytes,
+                        float* w_flat, float* m_flat, float* v_flat, float lr, float b1, float b2, float eps, int32_t* step_dev,
+                        float weight_decay, void* stream);
 
 /* Readout of a last layer kept as channel blocks (hidden widths above 32): logits are linear in H, so the blocks' logits
  * (scn_readout_forward per block with its rows of W_last) are added and normalised here:
@@ -434,6 +445,15 @@ int scn_masked_ce_begin(int64_t n, const float* logp, const float* y, float scal
 int scn_adam_step(int64_t n, float* w, const float* g, float* m, float* v,
                   float lr, float b1, float b2, float eps, int32_t step_i,
                   float weight_decay, float g_scale, void* stream);
+/* The same update with the step index in device memory: reads i = step_dev[0], applies update i, leaves i + 1 in step_dev[0].
+ * The launch's arguments do not change from step to step, so it can be captured into a HIP graph behind the gradient launches
+ * (scone_trajectory_model.py does, on one rank: the plain launch after a graph replay costs ~8 us of an ~80 us step on the
+ * reference's own problem sizes).  One workgroup: n <= SCN_ADAM_DEV_MAX (every model of the reference is far below),
+ * SCN_ERR_UNSUPPORTED beyond.  Bitwise the same weights as scn_adam_step(step_i = i). */
+#define SCN_ADAM_DEV_MAX 65536
+int scn_adam_step_dev(int64_t n, float* w, const float* g, float* m, float* v,
+                      float lr, float b1, float b2, float eps, int32_t* step_dev,
+                      float weight_decay, float g_scale, void* stream);
 
 #ifdef __cplusplus
 }

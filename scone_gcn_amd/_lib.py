@@ -123,10 +123,16 @@ SIGNATURES = {
     "scn_small_step": (ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_f32, c_void_p,
                                       c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_i32,
                                       ctypes.POINTER(c_void_p), c_void_p, c_i32, c_void_p, c_size_t, c_void_p]),
+    "scn_small_step_adam": (ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_f32, c_void_p,
+                                           c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_i32,
+                                           ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_size_t,
+                                           c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32, c_void_p, c_f32, c_void_p]),
     "scn_masked_ce": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_f32, c_void_p, c_void_p, c_void_p]),
     "scn_masked_ce_begin": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_f32, c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p]),
     "scn_adam_step": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
                                      c_i32, c_f32, c_f32, c_void_p]),
+    "scn_adam_step_dev": (ctypes.c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_f32, c_f32, c_f32, c_f32,
+                                         c_void_p, c_f32, c_f32, c_void_p]),
 }
 
 _lib = None

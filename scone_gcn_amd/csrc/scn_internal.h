@@ -64,6 +64,25 @@ __device__ __forceinline__ float act_grad_from_output(int act, float y) {
     }
 }
 
+// One parameter's ridge + Adam update (scn_adam_step, STM:300-326), every multiply-add spelled out: all kernels that apply it must round
+// alike (left to the compiler's contraction, `a * b + c * d` became fma(a, b, c * d) in one kernel and fma(c, d, a * b) in another).
+// c1 = 1 - b1^(i+1), c2 = 1 - b2^(i+1) (adam_corrections); wd2 = 2 * weight_decay.
+__device__ __forceinline__ void adam_update(float* __restrict__ w, float g_raw, float* __restrict__ m, float* __restrict__ v, float lr,
+                                            float b1, float b2, float eps, float c1, float c2, float wd2, float g_scale) {
+#pragma clang fp contract(off)
+    const float wi = *w;
+    const float gi = fmaf(g_raw, g_scale, wd2 * wi);
+    const float mi = fmaf(1.f - b1, gi, b1 * *m);
+    const float vi = fmaf((1.f - b2) * gi, gi, b2 * *v);
+    *m = mi;
+    *v = vi;
+    *w = wi - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+}
+__host__ __device__ __forceinline__ void adam_corrections(float b1, float b2, int i, float& c1, float& c2) {
+    c1 = 1.f - (float)pow((double)b1, (double)(i + 1));
+    c2 = 1.f - (float)pow((double)b2, (double)(i + 1));
+}
+
 struct Group {
     int32_t n_cols = 0, identity = 0, n_vals = 0;
     int64_t nnz = 0;

@@ -585,13 +585,25 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ w, const float* __res
                             float wd2, float g_scale) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const float wi = w[t];
-    const float gi = fmaf(g[t], g_scale, wd2 * wi);
-    const float mi = (1.f - b1) * gi + b1 * m[t];
-    const float vi = (1.f - b2) * gi * gi + b2 * v[t];
-    m[t] = mi;
-    v[t] = vi;
-    w[t] = wi - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+    adam_update(w + t, g[t], m + t, v + t, lr, b1, b2, eps, c1, c2, wd2, g_scale);
+}
+
+// The same update (adam_update, scn_internal.h) with the step index in DEVICE memory: one workgroup (the flat buffer of every model of the reference is a few
+// thousand floats), which reads step[0] = i, applies update i and leaves i + 1 there -- a launch whose arguments never change, so
+// the optimiser step can sit inside a captured graph behind the gradient launches (on the reference's own problem sizes the
+// hand-over from a graph replay to a plain launch is ~8 us of an ~80 us step).
+constexpr int ADAM_DEV_THREADS = 1024;
+__global__ __launch_bounds__(ADAM_DEV_THREADS) void adam_dev_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g,
+                                                                  float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                                                  float b2, float eps, int32_t* step, float wd2, float g_scale) {
+    __shared__ float c[2];
+    const int i = step[0];                                       // (every thread, before the barrier: thread 0 writes it after the last one)
+    if (threadIdx.x == 0) adam_corrections(b1, b2, i, c[0], c[1]);
+    __syncthreads();
+    const float c1 = c[0], c2 = c[1];
+    for (int64_t t = threadIdx.x; t < n; t += ADAM_DEV_THREADS) adam_update(w + t, g[t], m + t, v + t, lr, b1, b2, eps, c1, c2, wd2, g_scale);
+    __syncthreads();
+    if (threadIdx.x == 0) step[0] = i + 1;
 }
 
 }  // namespace scn
@@ -784,10 +796,21 @@ int scn_adam_step(int64_t n, float* w, const float* g, float* m, float* v, float
                   int32_t step_i, float weight_decay, float g_scale, void* stream) {
     if (n <= 0 || step_i < 0) return SCN_ERR_BAD_SHAPE;
     if (!w || !g || !m || !v) return SCN_ERR_BAD_ARG;
-    const float c1 = 1.f - powf(b1, (float)(step_i + 1));
-    const float c2 = 1.f - powf(b2, (float)(step_i + 1));
+    float c1, c2;
+    adam_corrections(b1, b2, step_i, c1, c2);            // (as the kernels that read the index from device memory: the same bits)
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, w, g, m,
                        v, lr, b1, b2, eps, c1, c2, 2.f * weight_decay, g_scale);
+    SCN_LAUNCH_CHECK();
+    return SCN_OK;
+}
+
+int scn_adam_step_dev(int64_t n, float* w, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                      int32_t* step_dev, float weight_decay, float g_scale, void* stream) {
+    if (n <= 0) return SCN_ERR_BAD_SHAPE;
+    if (n > SCN_ADAM_DEV_MAX) return SCN_ERR_UNSUPPORTED;
+    if (!w || !g || !m || !v || !step_dev) return SCN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(1), dim3(ADAM_DEV_THREADS), 0, (hipStream_t)stream, n, w, g, m, v, lr, b1, b2, eps,
+                       step_dev, 2.f * weight_decay, g_scale);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
 }

@@ -78,6 +78,7 @@ struct SmallArgs {
     int32_t n_traj, tag;
     float* xg;                                        // [n_layers - 1][N][E][16]  H_L, then the dx of layers L .. 3
     int* flags;                                       // [N][2 SM_MAX_LAYERS][2]   phase p of half h has been stored (= tag)
+    int32_t* step;                                    // scn_small_step_adam: [0] the next optimiser step's index, [1] the one in flight (or null)
 };
 
 __host__ __device__ static inline int small_pw(int n_layers) { return 3 * SM_C + (n_layers - 1) * SM_LAYER_W + SM_C; }
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_step_kernel(SmallArgs a) {
     int* const flags_n = PAIRED ? a.flags + (size_t)n * (4 * SM_MAX_LAYERS) : nullptr;
     float* const xg_n = PAIRED ? a.xg + (size_t)n * E * SM_C : nullptr;
     if (PAIRED && tid == 0) *fail = 0;
+    if (a.step && blockIdx.x == 0 && tid == 0) a.step[1] = a.step[0];      // (small_reduce_kernel applies update step[1] and advances step[0])
     // phase p of this half is in memory: called by every thread after a barrier that followed the wave's s_waitcnt vmcnt(0)
     auto post = [&](int phase) {
 #ifdef SM_AB_DROP_POST                                           // (diagnostic build, tools/small_pair_timeout.sh: a partner that never arrives)
@@ -841,6 +843,10 @@ struct SmallReduce {
     double* loss;
     int* flags;                                       // paired form: the hand-over flags go back to zero for the next launch / replay
     int32_t n_flags;
+    // scn_small_step_adam: the optimiser step on the summed gradient by the thread that has it (w null: none)
+    float* w; float* m; float* v;                     // flat, in the order of the outputs o
+    float lr, b1, b2, eps, wd2, g_scale;
+    int32_t* step;
 };
 __global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
     __shared__ float part[256];
@@ -851,6 +857,8 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
     if (o < a.pw)
         for (int n = g; n < a.n_traj; n += 16) acc += a.partial[(size_t)n * a.pw + o];
     part[g * 16 + oo] = acc;
+    __shared__ float cc[2];
+    if (a.w && threadIdx.x == 0) adam_corrections(a.b1, a.b2, a.step[1], cc[0], cc[1]);
     __syncthreads();
     if (g == 0 && o < a.pw) {
         float sum = 0.f;
@@ -859,8 +867,11 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(SmallReduce a) {
         int k = 0;
         while (k + 1 < a.n_w && o >= a.off[k + 1]) ++k;
         float* d = a.dW[k] + (o - a.off[k]);
-        *d = a.overwrite ? sum : *d + sum;
+        const float grad = a.overwrite ? sum : *d + sum;
+        *d = grad;
+        if (a.w) adam_update(a.w + o, grad, a.m + o, a.v + o, a.lr, a.b1, a.b2, a.eps, cc[0], cc[1], a.wd2, a.g_scale);
     }
+    if (a.w && blockIdx.x == 0 && threadIdx.x == 0) a.step[0] = a.step[1] + 1;      // (step[1] was set by small_step_kernel; nobody reads [0] here)
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         double accd = 0.0;
         for (int n = threadIdx.x; n < a.n_traj; n += 64) accd += a.loss_part[n];
@@ -1017,11 +1028,19 @@ int scn_small_step_pairing(int32_t mode) {
     return SCN_OK;
 }
 
-int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
-                   const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
-                   int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
-                   const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+struct SmallAdam {
+    float* w; float* m; float* v;
+    float lr, b1, b2, eps, weight_decay, g_scale;
+    int32_t* step;
+};
+
+static int small_step_impl(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                           const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                           int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                           const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
+                           size_t workspace_bytes, void* stream, const SmallAdam* adam) {
     if (!conv || !conv_t || !x || !last_nodes || !y || !nbr || !inc_ptr || !inc_edge || !inc_sign || !W || !dW || !loss || !workspace)
         return SCN_ERR_BAD_ARG;
     if (n_slabs <= 0 || ns <= 0 || n_nodes <= 0 || act < 0 || act > 3) return SCN_ERR_BAD_SHAPE;
@@ -1060,6 +1079,7 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     ws += (size_t)(n_layers - 1) * N * E * SM_C * 4;
     a.flags = (int*)ws;
     a.n_traj = N;
+    a.step = adam ? adam->step : nullptr;
     const bool paired = small_paired(E, N);
     if (paired) {
         // A fresh word per launch, never zero (the flags' resting value: small_reduce_kernel puts them back, so a graph replay -- same
@@ -1098,9 +1118,44 @@ int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t 
     }
     r.off[r.n_w] = off;
     r.partial = a.partial; r.loss_part = a.loss_part; r.loss = loss;
+    if (adam) {
+        r.w = adam->w; r.m = adam->m; r.v = adam->v;
+        r.lr = adam->lr; r.b1 = adam->b1; r.b2 = adam->b2; r.eps = adam->eps;
+        r.wd2 = 2.f * adam->weight_decay; r.g_scale = adam->g_scale;
+        r.step = adam->step;
+    }
     hipLaunchKernelGGL(small_reduce_kernel, dim3((pw + 15) / 16), dim3(256), 0, s, r);
     SCN_LAUNCH_CHECK();
     return SCN_OK;
+}
+
+extern "C" {
+
+int scn_small_step(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                   const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                   int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                   const float* const* W, int32_t act, float* const* dW, double* loss, int32_t overwrite, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    return small_step_impl(conv, conv_t, n_slabs, ns, n_layers, hidden, x, last_nodes, y, scale, nbr, n_nodes, max_deg, max_items,
+                           inc_ptr, inc_edge, inc_sign, W, act, dW, loss, overwrite, workspace, workspace_bytes, stream, nullptr);
+}
+
+int scn_small_step_adam(scn_conv_t conv, scn_conv_t conv_t, int32_t n_slabs, int32_t ns, int32_t n_layers, int32_t hidden,
+                        const float* x, const int32_t* last_nodes, const float* y, float scale, const int32_t* nbr, int32_t n_nodes,
+                        int32_t max_deg, int32_t max_items, const int32_t* inc_ptr, const int32_t* inc_edge, const float* inc_sign,
+                        const float* const* W, int32_t act, float* const* dW, double* loss, void* workspace, size_t workspace_bytes,
+                        float* w_flat, float* m_flat, float* v_flat, float lr, float b1, float b2, float eps, int32_t* step_dev,
+                        float weight_decay, void* stream) {
+    if (!w_flat || !m_flat || !v_flat || !step_dev || !W) return SCN_ERR_BAD_ARG;
+    if (n_layers < 2 || n_layers > SM_MAX_LAYERS) return SCN_ERR_UNSUPPORTED;
+    int off = 0;
+    for (int k = 0; k < 3 * n_layers + 1; ++k) {                // the weights as ONE flat buffer in the order of the list
+        if (W[k] != w_flat + off) return SCN_ERR_BAD_ARG;
+        off += k < 3 ? SM_C : (k < 3 * n_layers ? SM_C * SM_C : SM_C);
+    }
+    const SmallAdam ad{w_flat, m_flat, v_flat, lr, b1, b2, eps, weight_decay, 1.f, step_dev};
+    return small_step_impl(conv, conv_t, n_slabs, ns, n_layers, hidden, x, last_nodes, y, scale, nbr, n_nodes, max_deg, max_items,
+                           inc_ptr, inc_edge, inc_sign, W, act, dW, loss, 1, workspace, workspace_bytes, stream, &ad);
 }
 
 }  // extern "C"

@@ -953,11 +953,13 @@ class SconePlan:
         return op.plan_info()[0] > 0
 
     # -- small complexes: the whole gradient step of a micro-batch in one launch (scn_small_step, csrc/scn_small.hip)
-    def small_step(self, x, last_dev, yt, scale, weights, grads, loss, overwrite=False):
+    def small_step(self, x, last_dev, yt, scale, weights, grads, loss, overwrite=False, adam=None):
         """grads[k] += d/dW[k] of scale * sum_n <logp_n, yt_n> and loss[0] += that sum, with one workgroup per trajectory keeping
         the activations in LDS through all layers and both directions (the reference's own sizes, TE:86-90).  False when the
         shape is not served (hidden width other than 16, a complex too large for the LDS, ...): the caller then runs
-        forward / scn_masked_ce / backward.  overwrite: grads and loss are SET instead of accumulated into."""
+        forward / scn_masked_ce / backward.  overwrite: grads and loss are SET instead of accumulated into.
+        adam (with overwrite): (flat_w, m, v, lr, weight_decay, step_dev) -- the launch that sums the gradient also applies the
+        optimiser step to the flat weight buffer `weights` are views of (scn_small_step_adam)."""
         if not SMALL_STEP or self.conv is None or self.conv.n_groups != 1 or len(weights) < 7 or (len(weights) - 1) % 3:
             return False
         L = (len(weights) - 1) // 3
@@ -974,6 +976,19 @@ class SconePlan:
         ws = torch.empty(int(lib.scn_small_step_workspace(E, S * ns, L)), device=x.device, dtype=torch.uint8)
         # bytes the launch has to move at least: the input flows, the saved activations written and read back, the operator
         nb = x.numel() * 4 + 2 * (L - 1) * S * ns * E * hidden * 4 + self.conv.csr_bytes
+        if adam is not None:
+            assert overwrite, "the fused optimiser step takes the whole gradient of the batch"
+            flat_w, m, v, lr, wd, step_dev = adam
+            with _timed("small_step L%d c%d" % (L, hidden), nb):
+                check(lib.scn_small_step_adam(self.conv.handle, self.conv_T.handle, S, ns, L, hidden, _dev(x), _dev(last_dev, torch.int32),
+                                              _dev(yt), float(scale), _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,
+                                              self.max_items, _dev(self.inc_ptr, torch.int32), _dev(self.inc_edge, torch.int32),
+                                              _dev(self.inc_sign), ptr_array([_dev(w).value for w in weights]), ACT[self.act],
+                                              ptr_array([_dev(g).value for g in grads]), ctypes.c_void_p(loss.data_ptr()),
+                                              ctypes.c_void_p(ws.data_ptr()), ws.numel(), _dev(flat_w), _dev(m), _dev(v), float(lr),
+                                              0.9, 0.999, 1e-8, ctypes.c_void_p(step_dev.data_ptr()), float(wd), _stream()),
+                      "scn_small_step_adam")
+            return True
         with _timed("small_step L%d c%d" % (L, hidden), nb):
             check(lib.scn_small_step(self.conv.handle, self.conv_T.handle, S, ns, L, hidden, _dev(x), _dev(last_dev, torch.int32),
                                      _dev(yt), float(scale), _dev(self.nbr, torch.int32), self.n_nodes, self.max_deg,

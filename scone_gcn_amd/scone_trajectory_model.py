@@ -180,6 +180,8 @@ class Scone_GCN():
         self._flat_g = torch.zeros_like(self._flat_w)
         self._m = torch.zeros_like(self._flat_w)
         self._v = torch.zeros_like(self._flat_w)
+        self._step_dev = torch.zeros(2, device=device, dtype=torch.int32)      # [0] the step index where scn_adam_step_dev reads it ([1]: scratch)
+        self._step_dev_value = 0                                              # ... and what it holds (host mirror)
         self._offsets = np.concatenate([[0], np.cumsum(sizes)])
         self._shapes = [tuple(w.shape) for w in host_weights]
         self.weights = self._views(self._flat_w)
@@ -382,10 +384,13 @@ class Scone_GCN():
             staged.append((x, last_dev, yt, activity))
         return staged
 
-    def _accumulate_staged(self, plan, staged, total, fresh=False):
+    def _accumulate_staged(self, plan, staged, total, fresh=False, adam=False):
         """flat_g += d/dW of  -sum_n <logp_n, y_n> / total over the staged micro-batches (fresh: flat_g = ..., i.e. zeroed first).
-        Returns that partial loss as a 0-dim device tensor (no host synchronisation inside the step)."""
+        Returns that partial loss as a 0-dim device tensor (no host synchronisation inside the step).
+        adam (callers: _adam_in_graph): the optimiser step follows at once -- when the batch is one micro-batch on the one-launch
+        step, its summing launch applies it (self._adam_applied says whether it did)."""
         lib = _lib.load()
+        self._adam_applied = False
         # The loss accumulator and (fresh) the gradient buffer are initialised BY the first launch that writes them -- the one-launch
         # step's overwrite form, or the first loss launch of the layer path (scn_masked_ce_begin) -- not by fill launches of their own:
         # on the reference's own sizes a step is ~15 launches of 5-15 us each.
@@ -396,8 +401,12 @@ class Scone_GCN():
                 if not part_set and not zero_g:
                     part.zero_()                                  # (accumulating call whose first micro-batch takes the one-launch step)
                     part_set = True
-                if plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part, overwrite=not part_set):
+                fuse = bool(adam) and len(staged) == 1 and not part_set
+                if plan.small_step(x, last_dev, yt, -1.0 / total, self.weights, self._grads, part, overwrite=not part_set,
+                                   adam=(self._flat_w, self._m, self._v, self.step_size, self.weight_decay, self._step_dev)
+                                   if fuse else None):
                     part_set, zero_g = True, False
+                    self._adam_applied = fuse
                     continue
             logp, saved = plan.forward(x, last_dev, self.weights, activity) if activity else plan.forward(x, last_dev, self.weights)
             d_logp = torch.empty_like(logp)
@@ -435,13 +444,22 @@ class Scone_GCN():
         rows = sum(plan.sizes) if type(plan) is ops.BunchPlan else plan.n_edges
         return rows * ops.pad_count(n_traj) * (plan.promotion(self.weights) or widest) <= self.GRAPH_MAX_ELEMS
 
-    def _graph_accumulate(self, plan, staged, total, prologue=None, key_extra=()):
+    def _adam_in_graph(self, apply):
+        """The optimiser step rides inside the captured graph when nothing has to happen between the gradient and the update (one
+        rank: no all-reduce) and the step index can come from device memory (scn_adam_step_dev)."""
+        return (bool(apply) and self._adam_on_device() and not self.collective_always
+                and dp.world(self.process_group)[1] == 1)
+
+    def _graph_accumulate(self, plan, staged, total, prologue=None, key_extra=(), adam=False):
         """flat_g = gradient of the staged micro-batch (as _accumulate_staged after zeroing flat_g), through a captured graph:
         the first call with a given (plan, buffers, total, weight buffer) runs eagerly -- which also warms every kernel up --
-        and captures; later calls replay.  The buffers of `staged` must keep their addresses (they are kept alive here)."""
+        and captures; later calls replay.  The buffers of `staged` must keep their addresses (they are kept alive here).
+        adam: the graph ends with the optimiser step (_adam_in_graph; the caller does the host bookkeeping, _adam_done)."""
         x, last_dev, yt, _ = staged[0]
         key = (id(plan), x.data_ptr(), last_dev.data_ptr(), yt.data_ptr(), tuple(x.shape), float(total), self._flat_w.data_ptr(),
-               self._flat_g.data_ptr(), tuple(self._shapes)) + tuple(key_extra)
+               self._flat_g.data_ptr(), tuple(self._shapes), bool(adam)) + tuple(key_extra)
+        if adam:
+            self._sync_step_dev()                        # (outside the graph: a fill launch, only when the host moved the index)
         hit = self._graphs.get(key)
         if hit is not None:
             hit[0].replay()
@@ -450,7 +468,10 @@ class Scone_GCN():
         def body():
             if prologue is not None:
                 prologue()
-            return self._accumulate_staged(plan, staged, total, fresh=True)
+            part = self._accumulate_staged(plan, staged, total, fresh=True, adam=adam)
+            if adam and not self._adam_applied:
+                self._adam_launch()
+            return part
         loss = body()                                    # eager: this call's result, and the warm-up of the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -465,7 +486,11 @@ class Scone_GCN():
         number of trajectories in the batch (all ranks)."""
         plan = self._plan(inputs)
         if len(staged) == 1 and staged[0][3] is None and self._graph_ok(plan, staged[0][0].shape[0] * ops.NS):
-            loss = self._graph_accumulate(plan, staged, total)
+            fused = self._adam_in_graph(apply)
+            loss = self._graph_accumulate(plan, staged, total, adam=fused)
+            if fused:
+                self._adam_done()
+                return loss
         else:
             loss = self._accumulate_staged(plan, staged, total, fresh=True)
         dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
@@ -498,7 +523,11 @@ class Scone_GCN():
             local = dp.shard_indices(idx, rank, ws)
             st = self._static_stage(plan, inputs, y)
             if st.load(local, inputs[1], y, len(idx)):        # False: more trajectories / flow entries than the buffers hold
-                loss = self._graph_accumulate(plan, [st.staged], 1.0, prologue=st.scatter, key_extra=("static",))
+                fused = self._adam_in_graph(apply)
+                loss = self._graph_accumulate(plan, [st.staged], 1.0, prologue=st.scatter, key_extra=("static",), adam=fused)
+                if fused:
+                    self._adam_done()
+                    return loss
                 dp.all_reduce_sum_(self._flat_g, self.process_group, force=self.collective_always)
                 if apply:
                     self._adam()
@@ -528,9 +557,41 @@ class Scone_GCN():
             self._adam()
         return data.detach().double()
 
+    ADAM_DEV_MAX = 65536                                 # SCN_ADAM_DEV_MAX (include/scone_hip.h): one workgroup's worth of parameters
+
+    def _adam_on_device(self):
+        return self._flat_w.numel() <= self.ADAM_DEV_MAX
+
+    def _sync_step_dev(self):
+        """The device copy of the step index follows self._step: the launch itself leaves i + 1 there, so this writes only after the
+        host moved the index (train() sets the LOOP index, STM:310; a skipped empty batch, a restart)."""
+        if self._step_dev_value != int(self._step):
+            self._step_dev[:1].fill_(int(self._step))
+            self._step_dev_value = int(self._step)
+
+    def _adam_launch(self):
+        """The launch alone (capturable: its arguments do not change from step to step)."""
+        _lib.check(_lib.load().scn_adam_step_dev(self._flat_w.numel(), ops._dev(self._flat_w), ops._dev(self._flat_g),
+                                                 ops._dev(self._m), ops._dev(self._v), float(self.step_size), 0.9, 0.999, 1e-8,
+                                                 ctypes.c_void_p(self._step_dev.data_ptr()), float(self.weight_decay), 1.0,
+                                                 ops._stream()), "scn_adam_step_dev")
+
+    def _adam_done(self):
+        """Host bookkeeping of one optimiser step taken on the device."""
+        self._step += 1
+        self._step_dev_value += 1
+        self._wver += 1                                 # (a raw-pointer write: invisible to torch's version counter)
+
     def _adam(self):
         """Fused ridge + Adam on the flat buffer: g + 2*wd*w, b1=.9, b2=.999, eps=1e-8 outside the sqrt, (i+1) bias
-        correction -- jax.experimental.optimizers.adam as driven by STM:300-326."""
+        correction -- jax.experimental.optimizers.adam as driven by STM:300-326.  The step index travels in device memory
+        (scn_adam_step_dev; the same bits as scn_adam_step) so that the graph-replayed step of small complexes can end with this very
+        launch; flat buffers beyond one workgroup's worth take the host-index form."""
+        if self._adam_on_device():
+            self._sync_step_dev()
+            self._adam_launch()
+            self._adam_done()
+            return
         lib = _lib.load()
         _lib.check(lib.scn_adam_step(self._flat_w.numel(), ops._dev(self._flat_w), ops._dev(self._flat_g),
                                      ops._dev(self._m), ops._dev(self._v), float(self.step_size), 0.9, 0.999, 1e-8,

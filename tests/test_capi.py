@@ -55,6 +55,11 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu(lib):
     assert lib.scn_adam_step(ctypes.c_int64(0), None, None, None, None, ctypes.c_float(1e-3), ctypes.c_float(.9),
                              ctypes.c_float(.999), ctypes.c_float(1e-8), 0, ctypes.c_float(0), ctypes.c_float(1),
                              None) == -2                                # SCN_ERR_BAD_SHAPE
+    f = ctypes.c_float
+    dev_args = (f(1e-3), f(.9), f(.999), f(1e-8))
+    assert lib.scn_adam_step_dev(ctypes.c_int64(0), None, None, None, None, *dev_args, None, f(0), f(1), None) == -2
+    assert lib.scn_adam_step_dev(ctypes.c_int64(8), None, None, None, None, *dev_args, None, f(0), f(1), None) == -1
+    assert lib.scn_adam_step_dev(ctypes.c_int64(65537), None, None, None, None, *dev_args, None, f(0), f(1), None) == -4   # one workgroup's worth
     assert lib.scn_conv_destroy(None) == 0
 
 

@@ -356,6 +356,47 @@ def test_trainer_step_matches_oracle_adam(cfg1, sc1):
             assert _maxdiff(a.cpu().numpy(), b) <= 2e-6, "step %d" % i
 
 
+def test_adam_with_the_step_index_in_device_memory_gives_the_bits_of_the_host_index_form():
+    """scn_adam_step_dev (reads i from device memory, leaves i + 1: the launch a captured graph can end with) against scn_adam_step
+    with the same index from the host: the same weights and moments bit for bit over consecutive steps, from a late index as well
+    (bias corrections 1 - b^(i+1) near their limits), and against the update formula in fp64 (STM:300-326)."""
+    import ctypes
+    from scone_gcn_amd import _lib, ops
+    lib = _lib.load()
+    dev = ops.default_device()
+    rs = np.random.RandomState(5)
+    n = 6272
+    w0 = torch.tensor(rs.randn(n).astype(np.float32) * 0.1, device=dev)
+    for start in (0, 4096):
+        bufs = {}
+        for form in ("host", "dev"):
+            w, m, v = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
+            step = torch.full((1,), start, device=dev, dtype=torch.int32)
+            rg = np.random.RandomState(9)
+            for i in range(start, start + 4):
+                g = torch.tensor(rg.randn(n).astype(np.float32) * 1e-2, device=dev)
+                if form == "host":
+                    st = lib.scn_adam_step(n, ops._dev(w), ops._dev(g), ops._dev(m), ops._dev(v), 1e-3, 0.9, 0.999, 1e-8, i, 5e-5, 1.0,
+                                           ops._stream())
+                else:
+                    st = lib.scn_adam_step_dev(n, ops._dev(w), ops._dev(g), ops._dev(m), ops._dev(v), 1e-3, 0.9, 0.999, 1e-8,
+                                               ctypes.c_void_p(step.data_ptr()), 5e-5, 1.0, ops._stream())
+                assert st == 0
+            bufs[form] = (w.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), int(step.item()))
+        assert bufs["dev"][3] == start + 4 and bufs["host"][3] == start
+        for a, b in zip(bufs["host"][:3], bufs["dev"][:3]):
+            assert np.array_equal(a, b)
+        # fp64 restatement of the four updates
+        w, m, v = w0.cpu().numpy().astype(np.float64), np.zeros(n), np.zeros(n)
+        rg = np.random.RandomState(9)
+        for i in range(start, start + 4):
+            g = (rg.randn(n).astype(np.float32) * 1e-2).astype(np.float64) + 2 * 5e-5 * w
+            m = 0.1 * g + 0.9 * m
+            v = 0.001 * g * g + 0.999 * v
+            w = w - 1e-3 * (m / (1 - 0.9 ** (i + 1))) / (np.sqrt(v / (1 - 0.999 ** (i + 1))) + 1e-8)
+        assert np.abs(bufs["dev"][0] - w).max() <= 2e-6
+
+
 def test_loss_accuracy_and_reverse_inputs(cfg1, sc1):
     from scone_gcn_amd import trajectory_experiments as te
     from scone_gcn_amd import scone_trajectory_model as stm

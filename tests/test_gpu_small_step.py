@@ -177,6 +177,34 @@ def test_small_step_inside_the_replayed_graph(cfg1, sc1):
         assert la == lb and np.array_equal(ga, gb) and np.array_equal(wa, wb)
 
 
+def test_optimiser_step_inside_the_summing_launch_gives_the_bits_of_the_separate_one(cfg1, sc1):
+    """scn_small_step_adam (one micro-batch, one rank: the launch that sums the weight gradient applies the ridge + Adam update, the
+    step index read from device memory) against the same gradient launches followed by scn_adam_step_dev (net.collective_always
+    keeps the update out of the gradient launches): weights, moments, gradients and loss bit for bit over four steps, replayed and
+    eager, with the step index moved by the host in between (train() sets the loop index, STM:310)."""
+    res = {}
+    for graph in (False, True):
+        for fused in (True, False):
+            net, inputs, _ = _net(sc1, cfg1, "scone", [(3, 16)] * 3, 8.0, True, graph=graph)
+            net.collective_always = not fused
+            staged = net.stage(inputs, cfg1["targets"], np.arange(10, 110))
+            out = []
+            for i in range(4):
+                if i == 2:
+                    net._step = 7                                     # the host moves the index: the device copy has to follow
+                loss = float(net.grad_step_staged(inputs, staged, 100))
+                out.append((loss, net._flat_g.cpu().numpy().copy(), net._flat_w.cpu().numpy().copy(), net._m.cpu().numpy().copy(),
+                            net._v.cpu().numpy().copy(), int(net._step_dev[0].item()), net._step))
+            assert out[-1][5] == 9 and out[-1][6] == 9
+            assert net._adam_in_graph(True) == fused
+            res[(graph, fused)] = out
+    ref = res[(False, False)]
+    assert np.abs(ref[-1][2] - ref[0][2]).max() > 1e-4
+    for key, out in res.items():
+        for a, b in zip(out, ref):
+            assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:5], b[1:5])), key
+
+
 _FIRST_CALL_SCRIPT = r"""
 import sys
 import numpy as np, torch
