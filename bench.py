@@ -427,8 +427,8 @@ def compact_line(line, limit=COMPACT_LIMIT):
         cf[name] = {"value": c.get("value"), "ms_per_step": c.get("ms_per_step"), "kernel": r.get("kernel"), "frac": r.get("frac")}
         if r.get("traffic"):
             cf[name]["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
-        if "one_launch_step" in c:
-            cf[name]["one_launch_ms_per_step"] = c["one_launch_step"].get("ms_per_step")
+        if "layer_kernels_step" in c:
+            cf[name]["layer_kernels_ms_per_step"] = c["layer_kernels_step"].get("ms_per_step")
     if cf:
         optional.append(("configs", cf))
     sm = line.get("step_model")
@@ -748,17 +748,18 @@ def main():
         cx0 = g.random_SC_graph(400)
         configs["configs[0]"] = side_config("BASELINE configs[0]: synthetic_data_gen.py 400-point complex, 3-layer SCoNe hidden 16, batch 100 "
                                             "(the reference's own problem size; its dense-faithful CPU restatement is cpu_baseline.dense_faithful_configs0)",
-                                            "scone", cx0, SimplicialComplex(cx0), 16, 100, 50, sync)
-        # the same case on the one-launch step (ops.small_step_pays leaves batch 100 at |E| = 1001 on the layer kernels: it ties them there)
-        keep = ops.SMALL_STEP_MAX_EDGES
-        ops.SMALL_STEP_MAX_EDGES = 1 << 30
+                                            "scone", cx0, SimplicialComplex(cx0), 16, 100, 1000, sync)
+        # the same case on the layer-by-layer kernels (the default is the one-launch step with two workgroups per trajectory; a step is
+        # ~80 us, so a thousand of them: the queue's start-up and the final synchronisation are ~100 us)
+        keep = ops.SMALL_STEP
+        ops.SMALL_STEP = False
         try:
-            forced = side_config("configs[0] with scn_small_step forced (one launch per micro-batch)", "scone", cx0, SimplicialComplex(cx0),
-                                 16, 100, 50, sync)
-            configs["configs[0]"]["one_launch_step"] = {"ms_per_step": forced["ms_per_step"], "value": forced["value"],
-                                                        "unit": forced["unit"], "kernels": forced["kernels"]}
+            layers_ = side_config("configs[0] on the layer-by-layer kernels (ops.SMALL_STEP = False)", "scone", cx0, SimplicialComplex(cx0),
+                                  16, 100, 1000, sync)
+            configs["configs[0]"]["layer_kernels_step"] = {"ms_per_step": layers_["ms_per_step"], "value": layers_["value"],
+                                                           "unit": layers_["unit"], "kernels": layers_["kernels"]}
         finally:
-            ops.SMALL_STEP_MAX_EDGES = keep
+            ops.SMALL_STEP = keep
         # configs[2]: ocean drifters, full training batch (the trajectories of tests/golden/buoy.npz)
         bpath = os.path.join(ROOT, "tests", "golden", "buoy.npz")
         if os.path.exists(bpath):
@@ -773,7 +774,7 @@ def main():
             y3 = np.zeros((len(tr), sc3.max_degree, 1))
             y3[np.arange(len(tr)), ch3[tr], 0] = 1.0
             configs["configs[2]"] = side_config("BASELINE configs[2]: ocean drifters, 3-layer SCoNe hidden 16, full training batch",
-                                                "scone", cx3, sc3, 16, len(tr), 20, sync,
+                                                "scone", cx3, sc3, 16, len(tr), 1000, sync,
                                                 data=(fl3.select(tr), ch3[tr], last3[tr], y3))
         line["configs"] = configs
 

@@ -462,7 +462,7 @@ def _synthetic_full_record(n_configs=12, pad=400):
             "dense_random_bwd_frac": 0.3987552937851131, "dense_random_bwd_ms": 15.400796890258789}
     kernels = {"conv_fwd c%d->32" % i: {"launches": 32, "avg_ms": 3.3347, "GB/s": 5000.1} for i in range(8)}
     side = {"workload": "w" * pad, "model": "scone", "value": 5486.308846631601, "ms_per_step": 23.330804659053683, "unit": "trajectories/s",
-            "roofline": dict(roof), "kernels": kernels, "step_model": {"a": 1.0}, "one_launch_step": {"ms_per_step": 0.119, "value": 1.0}}
+            "roofline": dict(roof), "kernels": kernels, "step_model": {"a": 1.0}, "layer_kernels_step": {"ms_per_step": 0.119, "value": 1.0}}
     return {"metric": "trajectories/sec fwd+bwd, 3-layer SCoNe |E|~1M batch=4096; SpMM HBM GB/s", "value": 3035.612345678, "unit": "trajectories/s",
             "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 1349.3123456, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
