@@ -2,7 +2,7 @@
 """Diagnostic: run fwd_c32 / bwd_c32 from the -DSCN_STAMPS build (tools/build_stamps.sh) and print where a wave's cycles go per
 slab iteration -- over all waves, and per wave INDEX of the workgroup (who waits at the slab barrier, who arrives last).
 
-    python tools/stamps.py [fwd] [bwd] [bwdf] [dense] [sparse]
+    python tools/stamps.py [fwd] [bwd] [bwdf] [dense] [sparse] [zeros]
 """
 import ctypes, os, sys
 os.environ["SCN_LIB_PATH"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libscone_hip_stamps.so")
@@ -19,11 +19,14 @@ E, C, S = cx.n_edges, 32, 32
 W = [torch.randn(C, C, device="cuda") * 0.1 for _ in range(3)]
 W1 = [torch.randn(1, C, device="cuda") * 0.1 for _ in range(3)]
 kinds = [a for a in sys.argv[1:] if a in ("fwd", "bwd", "bwdf")] or ["fwd"]
-datas = [a for a in sys.argv[1:] if a in ("dense", "sparse")] or ["dense"]
+datas = [a for a in sys.argv[1:] if a in ("dense", "sparse", "zeros")] or ["dense"]
 for data in datas:
     x = torch.randn(S, E, 4, C, device="cuda")
     if data == "sparse":      # like the benchmark's activations: ~5 % of the 64-row groups of a slab carry values, the rest are exact zeros
         keep = (torch.rand(S, (E + 63) // 64, device="cuda") < 0.05).repeat_interleave(64, dim=1)[:, :E]
+        x *= keep[:, :, None, None]
+    if data == "zeros":       # nearer to a real batch still: 0.2 % of the groups
+        keep = (torch.rand(S, (E + 63) // 64, device="cuda") < 0.002).repeat_interleave(64, dim=1)[:, :E]
         x *= keep[:, :, None, None]
     aux = torch.tanh(x)
     for which in kinds:
