@@ -72,6 +72,8 @@ def call(plan, k, x, aux, yrec):
         return [o for o in out if o is not None] + [d for row in dWn for d in row if d is not None]
     if k == "spmm":
         return plan.conv.spmm_dual(x.view(S, E, 4 * C))
+    if k == "fwd1":                                  # the first layer: one input channel (x[..., :1]) -> C
+        return plan.conv.forward_first(x1, W1, C, "tanh", out=out1, y=y1)
     if k == "fwd":
         return plan.conv.forward([x], W, C, "tanh")
     if k == "bwd":
@@ -108,6 +110,10 @@ for data in a.data.split(","):
         x *= keep[:, :, None, None]
     aux = torch.tanh(torch.randn(S, E, 4, C, device=dev))
     yrec = torch.randn(S, E, 4, 4, device=dev)
+    if "fwd1" in which:
+        x1 = x[..., :1].contiguous()
+        out1 = torch.empty(S, E, 4, C, device=dev)
+        y1 = torch.empty(S, E, 4, 4, device=dev)
     times = {(k, n): [] for k in which for n in builds}
     for k in which:
         for n, (lib, plan) in builds.items():

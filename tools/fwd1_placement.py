@@ -40,10 +40,18 @@ for off in (0, 64, 256, 1024, 4096, 65536, 1 << 20, (1 << 20) + 4096, 1 << 21, 3
 del big
 print("fresh allocations after fillers of different sizes:", flush=True)
 keep = []
-for filler in (0, 1 << 20, 3 << 20, 1 << 28, 1 << 30, 5 << 30, 17 << 30):
+for filler in (0, 1 << 20, 3 << 20, 1 << 28, 1 << 30, 5 << 30, 17 << 30, 1 << 29, 7 << 30, 1 << 27, 9 << 30, 3 << 29):
     if filler:
         keep.append(torch.empty(filler, device=dev, dtype=torch.uint8))
     o = torch.empty(S, E, 4, C, device=dev)
-    print("   filler %-12d out at %#x: %.3f ms" % (filler, o.data_ptr(), timed(o, ybuf[:n_y].view(S, E, 4, 4))), flush=True)
+    t_k = timed(o, ybuf[:n_y].view(S, E, 4, 4))
+    o.zero_(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        o.zero_()
+    b.record(); torch.cuda.synchronize()
+    print("   filler %-12d out at %#x: %.3f ms   (torch zero_ of the same tensor: %.3f ms)" % (filler, o.data_ptr(), t_k, a.elapsed_time(b) / 5),
+          flush=True)
     del o
     torch.cuda.empty_cache()
