@@ -3,13 +3,14 @@
 400-point complex (|E| = 1001) with batches of changing size -- each size its own staged buffers and captured graph, visited in a
 shuffled order so that launches of different grids alternate on the same flag words -- and a check after every step that the loss is
 finite (a hand-over that timed out would make it NaN) plus, at the end, that a replay of the first step's batch still gives the
-first net's bits on a fresh net.  usage: python tools/small_pair_soak.py [steps=20000]"""
+first net's bits on a fresh net.  usage: python tools/small_pair_soak.py [steps=20000] [eager]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scone_gcn_amd import synthetic_data_gen as g, trajectory_experiments as te, scone_trajectory_model as stm
 from scone_gcn_amd.complex import SimplicialComplex
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+steps = int(next((v for v in sys.argv[1:] if v.isdigit()), 20000))
+eager = "eager" in sys.argv                                     # plain launches: the workspaces of different batch sizes share memory blocks
 cx = g.random_SC_graph(400); sc = SimplicialComplex(cx)
 M = 128
 paths = g.generate_random_walks(cx, m=M, seed=1)
@@ -23,6 +24,7 @@ def make():
     stm.reseed(1030)
     net = stm.Scone_GCN(1, 1e-3, M, 5e-5, verbose=False)
     net.GRAPH_CACHE = 16
+    net.use_graph = not eager
     net.setup(te.scone_func, [(3, 16)] * 3, shifts, inputs, y, None, np.ones(M, int), model_type="scone")
     return net
 
